@@ -1,0 +1,164 @@
+/*
+ * rt_abi.h -- C ABI of the MI355X (gfx950) wavefront path tracer.
+ *
+ * The Rust reference has no FFI of its own; the seam this library replaces is the
+ * tile-per-thread renderer `render()` (src/main.rs:319-416) together with the closest-hit
+ * query `Hittable::hit` (src/shape.rs:6-9) it is built on.  Because `Box<dyn Hittable>` and
+ * `Arc<dyn Material>` are opaque trait objects, a scene is *described* to the library with
+ * plain structs that mirror the reference types field by field; each entry point below cites
+ * the reference item it stands in for.
+ *
+ * Conventions: every call returns 0 on success or a negative rt_status; nothing throws or
+ * aborts across the boundary; rt_last_error() gives the message of the last failure on the
+ * calling thread.  Inputs are copied; the caller keeps ownership of everything it passes.
+ * Calls on one context must be serialised by the caller.  One context drives one GPU: a
+ * multi-GPU job runs one process (one context) per GPU and combines the per-GPU accumulation
+ * buffers with a single sum-reduce (RCCL), see rt_render_device().
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+typedef struct rt_scene rt_scene;
+
+typedef enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument */
+    RT_ERR_DEVICE = -2,       /* HIP runtime failure (no GPU, launch or copy failed) */
+    RT_ERR_STATE = -3,        /* call order (scene not committed, already committed, ...) */
+    RT_ERR_UNSUPPORTED = -4,  /* e.g. a non-identity mesh transform */
+    RT_ERR_NOMEM = -5
+} rt_status;
+
+/* material.rs:22-25 / 58-61 / 82-85 / 122-124 */
+enum { RT_MAT_LAMBERT = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_EMISSIVE = 3 };
+#define RT_MAT_FLAG_NORMAL_SHADING 1u  /* LambertianMaterial.normal (material.rs:24,48-52) */
+typedef struct {
+    uint32_t kind;   /* RT_MAT_* */
+    float rgb[3];    /* albedo, or emitted colour */
+    float param;     /* fuzz (metal) or ior (dielectric) */
+    uint32_t flags;
+} rt_material;
+
+/* shape.rs:11-15 */
+typedef struct { float c[3]; float r; uint32_t mat; } rt_sphere;
+
+/* shape.rs:165-183.  Only the first vertex normal is ever read (shape.rs:298). */
+typedef struct { float p[3][3]; float n0[3]; uint32_t mat; } rt_triangle;
+
+/* camera.rs:126-130 */
+typedef struct { float o[3]; float d[3]; } rt_ray;
+
+/* camera.rs:92-99 plus the primitive id the reference does not expose.  Primitive ids count
+ * objects in insertion order: a sphere takes one id, a mesh one id per triangle in the order
+ * the triangles were given. */
+#define RT_MISS 0xFFFFFFFFu
+typedef struct {
+    float t;
+    uint32_t prim_id;     /* RT_MISS when nothing was hit */
+    float p[3];
+    float n[3];           /* face-forwarded normal (camera.rs:112-119) */
+    uint32_t front_face;
+    uint32_t mat;
+} rt_hit;
+
+/* The fields Camera::setup() computes (camera.rs:17-24, 55-78). */
+typedef struct {
+    float origin[3], horizontal[3], vertical[3], lower_left[3], u[3], v[3];
+    float lens_radius;
+} rt_camera;
+
+/* What World.hittable is (main.rs:69-73): a Bvh over the object list (main.rs:170,234), the
+ * single object itself (main.rs:289) or a HittableList (shape.rs:55). */
+enum { RT_ROOT_BVH = 0, RT_ROOT_SINGLE = 1, RT_ROOT_LIST = 2 };
+
+/* main.rs:20-24 made run-time parameters, plus the partition this process renders. */
+typedef struct {
+    uint32_t width, height;            /* full frame */
+    uint32_t x0, y0, x1, y1;           /* pixel rectangle to render, [x0,x1) x [y0,y1) */
+    uint32_t sample_begin, sample_end; /* sample indices to render, [begin,end) */
+    uint32_t max_bounces;              /* MAX_BOUNCES (main.rs:21) */
+    float t_min;                       /* 0.001 in the reference (main.rs:46) */
+    float sky_intensity;               /* World.sky_intensity (main.rs:72) */
+    uint64_t seed;                     /* key of the counter-based RNG */
+    uint32_t flags;                    /* RT_RENDER_* */
+    uint32_t max_paths_in_flight;      /* 0 = library default */
+} rt_render_params;
+#define RT_RENDER_PROFILE 1u       /* time every closest-hit launch with HIP events */
+#define RT_RENDER_COUNT_VISITS 2u  /* count box / triangle / sphere tests (slower) */
+
+typedef struct {
+    uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */
+    uint64_t paths;          /* camera samples */
+    uint64_t box_tests, tri_tests, sph_tests;   /* with RT_RENDER_COUNT_VISITS */
+    uint64_t trace_launches; /* closest-hit kernel launches */
+    double ms_render;        /* wall time of the call on the GPU stream */
+    double ms_trace;         /* with RT_RENDER_PROFILE: summed closest-hit kernel time */
+    double ms_shade;         /* with RT_RENDER_PROFILE: summed shade kernel time */
+} rt_stats;
+
+/* ---- context: stands where ThreadPool::new() does (main.rs:443) ---------------------- */
+int rt_context_create(int device_id, rt_context** out);
+void rt_context_destroy(rt_context* ctx);
+const char* rt_last_error(void);
+/* the HIP stream the context launches on (a hipStream_t), for callers that order their own
+ * work (e.g. the RCCL reduce) after a render */
+void* rt_context_stream(rt_context* ctx);
+/* waits for everything queued on the context's stream */
+int rt_context_synchronize(rt_context* ctx);
+
+/* ---- scene: Sphere / Mesh::new / Bvh::new / HittableList (shape.rs) ------------------ */
+/* ctx may be NULL for a host-only scene: it can be filled, committed and inspected with
+ * rt_scene_get_entries(), but tracing or rendering it fails with RT_ERR_DEVICE */
+int rt_scene_create(rt_context* ctx, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+int rt_scene_set_materials(rt_scene* scene, const rt_material* mats, size_t n);
+/* each sphere is one object, appended in order (Vec<Box<dyn Hittable>>, main.rs:100-158) */
+int rt_scene_add_spheres(rt_scene* scene, const rt_sphere* spheres, size_t n);
+/* one Mesh object (Mesh::new, shape.rs:236-257).  xform is a column-major 4x4 or NULL for the
+ * identity; only the identity is supported (every shipped scene uses Mat4::identity()). */
+int rt_scene_add_mesh(rt_scene* scene, const rt_triangle* tris, size_t n, const float* xform);
+int rt_scene_set_root(rt_scene* scene, int root_kind);
+/* builds the reference-topology BVHs (shape.rs:94-138, 264-290), flattens them and uploads */
+int rt_scene_commit(rt_scene* scene);
+size_t rt_scene_num_prims(const rt_scene* scene);
+size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
+/* host-only scenes: copies the flattened pre-order entry array (12 floats per entry) */
+int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
+
+/* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */
+int rt_trace(rt_scene* scene, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out);
+/* same with device pointers; counts[3] (may be NULL, host memory) receives the box / triangle /
+ * sphere test totals of the batch */
+int rt_trace_device(rt_scene* scene, const void* d_rays, size_t n, float t_min, float t_max,
+                    void* d_hits, uint64_t* counts);
+
+/* ---- render: render() and its tile closure (main.rs:319-416) --------------------------- */
+/* Adds, for every pixel of the rectangle, the sum over the sample range of the path radiance
+ * (ray_color, main.rs:40-67) to accum_rgb (width*height*3 floats, linear, row-major, host
+ * memory).  The caller zeroes the buffer before the first call and divides by the sample
+ * count (or calls rt_tonemap) afterwards. */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
+              float* accum_rgb, rt_stats* stats);
+/* same, accumulating into a device buffer; returns after the work is queued and stats (if
+ * not NULL) forces a synchronise.  This is the call a multi-GPU job makes on every rank
+ * before it sum-reduces the buffers to rank 0. */
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
+                     void* d_accum_rgb, rt_stats* stats);
+
+/* ---- tonemap: main.rs:369-373 + rgb_to_u32 (math.rs:112-116) --------------------------- */
+int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out_0rgb, size_t npix);
+int rt_tonemap_device(rt_context* ctx, const void* d_accum_rgb, uint32_t spp, void* d_out_0rgb,
+                      size_t npix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,230 @@
+"""raytracer_amd -- ctypes binding of the MI355X wavefront path tracer's C ABI (include/rt_abi.h).
+
+The shared library librt_amd.so (HIP kernels for gfx950 + host scene builder) is the product;
+this module only marshals numpy arrays and device pointers across the C ABI.  There is no CPU
+fallback: if the library is missing the import fails, and every call that needs a GPU raises
+RtError when the HIP runtime reports none.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+ASSET_DIR = os.path.join(_HERE, "assets")
+
+MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
+MAT_FLAG_NORMAL_SHADING = 1
+ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
+MISS = 0xFFFFFFFF
+RENDER_PROFILE, RENDER_COUNT_VISITS = 1, 2
+DEFAULT_SEED = 0x9E3779B97F4A7C15
+
+material_dt = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("param", "<f4"), ("flags", "<u4")])
+sphere_dt = np.dtype([("c", "<f4", 3), ("r", "<f4"), ("mat", "<u4")])
+triangle_dt = np.dtype([("p", "<f4", (3, 3)), ("n0", "<f4", 3), ("mat", "<u4")])
+ray_dt = np.dtype([("o", "<f4", 3), ("d", "<f4", 3)])
+hit_dt = np.dtype([("t", "<f4"), ("prim_id", "<u4"), ("p", "<f4", 3), ("n", "<f4", 3),
+                   ("front_face", "<u4"), ("mat", "<u4")])
+camera_dt = np.dtype([("origin", "<f4", 3), ("horizontal", "<f4", 3), ("vertical", "<f4", 3),
+                      ("lower_left", "<f4", 3), ("u", "<f4", 3), ("v", "<f4", 3),
+                      ("lens_radius", "<f4")])
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32),
+                ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
+                ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
+                ("max_bounces", C.c_uint32), ("t_min", C.c_float), ("sky_intensity", C.c_float),
+                ("seed", C.c_uint64), ("flags", C.c_uint32), ("max_paths_in_flight", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_traced", C.c_uint64), ("paths", C.c_uint64), ("box_tests", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64), ("trace_launches", C.c_uint64),
+                ("ms_render", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C raytracer_amd/csrc`.  There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32, f32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_float, C.c_int
+    pp = C.POINTER(C.c_void_p)
+    sig = {
+        "rt_context_create": (i32, [i32, pp]),
+        "rt_context_destroy": (None, [vp]),
+        "rt_last_error": (C.c_char_p, []),
+        "rt_context_stream": (vp, [vp]),
+        "rt_context_synchronize": (i32, [vp]),
+        "rt_scene_create": (i32, [vp, pp]),
+        "rt_scene_destroy": (None, [vp]),
+        "rt_scene_set_materials": (i32, [vp, vp, sz]),
+        "rt_scene_add_spheres": (i32, [vp, vp, sz]),
+        "rt_scene_add_mesh": (i32, [vp, vp, sz, vp]),
+        "rt_scene_set_root": (i32, [vp, i32]),
+        "rt_scene_commit": (i32, [vp]),
+        "rt_scene_num_prims": (sz, [vp]),
+        "rt_scene_num_entries": (sz, [vp]),
+        "rt_scene_get_entries": (i32, [vp, vp, sz]),
+        "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
+        "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
+        "rt_render": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
+        "rt_render_device": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
+        "rt_tonemap": (i32, [vp, vp, u32, vp, sz]),
+        "rt_tonemap_device": (i32, [vp, vp, u32, vp, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+lib = _load()
+ABI_SYMBOLS = [
+    "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_context_stream",
+    "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
+    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_commit",
+    "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_trace",
+    "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
+]
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(f"rt error {rc}: {lib.rt_last_error().decode(errors='replace')}")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU (rt_context)."""
+
+    def __init__(self, device_id=0):
+        h = C.c_void_p()
+        _check(lib.rt_context_create(device_id, C.byref(h)))
+        self.h = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.rt_context_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib.rt_context_synchronize(self.h))
+
+    @property
+    def stream(self):
+        return lib.rt_context_stream(self.h)
+
+    def tonemap(self, accum, spp):
+        a = np.ascontiguousarray(accum, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(len(a), dtype=np.uint32)
+        _check(lib.rt_tonemap(self.h, _ptr(a), spp, _ptr(out), len(a)))
+        return out
+
+    def tonemap_device(self, d_accum, spp, d_out, npix):
+        _check(lib.rt_tonemap_device(self.h, d_accum, spp, d_out, npix))
+
+
+class Scene:
+    """rt_scene.  ctx=None gives a host-only scene (flattening can be inspected, nothing runs)."""
+
+    def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH):
+        self.ctx = ctx
+        h = C.c_void_p()
+        _check(lib.rt_scene_create(ctx.h if ctx is not None else None, C.byref(h)))
+        self.h = h
+        m = np.ascontiguousarray(materials, dtype=material_dt)
+        _check(lib.rt_scene_set_materials(self.h, _ptr(m), len(m)))
+        for kind, arr in objects:
+            if kind == "spheres":
+                a = np.ascontiguousarray(arr, dtype=sphere_dt)
+                _check(lib.rt_scene_add_spheres(self.h, _ptr(a), len(a)))
+            elif kind == "mesh":
+                a = np.ascontiguousarray(arr, dtype=triangle_dt)
+                _check(lib.rt_scene_add_mesh(self.h, _ptr(a), len(a), None))
+            else:
+                raise ValueError(kind)
+        _check(lib.rt_scene_set_root(self.h, root_kind))
+        _check(lib.rt_scene_commit(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.rt_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_prims(self):
+        return lib.rt_scene_num_prims(self.h)
+
+    @property
+    def num_entries(self):
+        return lib.rt_scene_num_entries(self.h)
+
+    def entries(self):
+        n = self.num_entries
+        out = np.zeros((n, 12), dtype=np.float32)
+        _check(lib.rt_scene_get_entries(self.h, _ptr(out), out.size))
+        return out
+
+    def trace(self, rays, t_min=0.001, t_max=np.inf):
+        rays = np.ascontiguousarray(rays, dtype=ray_dt)
+        out = np.zeros(len(rays), dtype=hit_dt)
+        _check(lib.rt_trace(self.h, _ptr(rays), len(rays), t_min, t_max, _ptr(out)))
+        return out
+
+    def trace_device(self, d_rays, n, d_hits, t_min=0.001, t_max=np.inf, count=False):
+        counts = (C.c_uint64 * 3)() if count else None
+        _check(lib.rt_trace_device(self.h, d_rays, n, t_min, t_max, d_hits, counts))
+        return tuple(counts) if count else None
+
+    @staticmethod
+    def params(width, height, spp, max_bounces, sky, rect=None, samples=None, seed=DEFAULT_SEED,
+               flags=0, t_min=0.001, max_paths=0):
+        x0, y0, x1, y1 = rect if rect is not None else (0, 0, width, height)
+        s0, s1 = samples if samples is not None else (0, spp)
+        return RenderParams(width, height, x0, y0, x1, y1, s0, s1, max_bounces, t_min, sky, seed,
+                            flags, max_paths)
+
+    def render(self, camera, params, accum=None):
+        """Host-buffer render; returns (accum[H,W,3] sums, stats dict)."""
+        cam = np.ascontiguousarray(camera, dtype=camera_dt).reshape(1)
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 3), dtype=np.float32)
+        st = Stats()
+        _check(lib.rt_render(self.h, _ptr(cam), C.byref(params), _ptr(accum), C.byref(st)))
+        return accum, st.as_dict()
+
+    def render_device(self, camera, params, d_accum, want_stats=True):
+        cam = np.ascontiguousarray(camera, dtype=camera_dt).reshape(1)
+        st = Stats()
+        _check(lib.rt_render_device(self.h, _ptr(cam), C.byref(params), d_accum,
+                                    C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None

@@ -1,0 +1,499 @@
+// C-ABI glue (include/rt_abi.h): contexts, scene upload, the host side of the wavefront loop.
+// There is no CPU fallback anywhere in this file: without a working HIP device every entry
+// point that needs one fails with RT_ERR_DEVICE.
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "rt_internal.hpp"
+
+using namespace rtamd;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+struct DeviceBuffer {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t grid_cap = 2048;
+    // wavefront state, grown on demand and kept between calls
+    DeviceBuffer rayA[2], rayB[2], rayC[2], hits, queue[3], lbuf, ctl, totals, scratch_in, scratch_out;
+    size_t capacity = 0;
+    std::vector<hipEvent_t> events;
+
+    LaunchCfg cfg() const { return LaunchCfg{(void*)stream, grid_cap}; }
+    ~rt_context() {
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+struct rt_scene {
+    rt_context* ctx = nullptr;
+    std::vector<rt_material> mats;
+    std::vector<SceneObject> objects;
+    int root_kind = RT_ROOT_BVH;
+    bool committed = false;
+    FlatScene flat;
+    DeviceBuffer d_entries, d_geo, d_meta, d_mats;
+    DevScene dev{};
+};
+
+namespace {
+
+int set_device(rt_context* ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int ensure_capacity(rt_context* ctx, size_t paths) {
+    if (paths <= ctx->capacity) return RT_OK;
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(ctx->rayA[k].ensure(paths * 16));
+        HIP_TRY(ctx->rayB[k].ensure(paths * 16));
+        HIP_TRY(ctx->rayC[k].ensure(paths * 16));
+    }
+    HIP_TRY(ctx->hits.ensure(paths * 8));
+    for (int k = 0; k < 3; k++) HIP_TRY(ctx->queue[k].ensure(paths * 4));
+    HIP_TRY(ctx->lbuf.ensure(paths * 16));
+    HIP_TRY(ctx->ctl.ensure(sizeof(BatchCtl)));
+    HIP_TRY(ctx->totals.ensure(sizeof(Totals)));
+    ctx->capacity = paths;
+    return RT_OK;
+}
+
+int get_events(rt_context* ctx, size_t n) {
+    while (ctx->events.size() < n) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        ctx->events.push_back(e);
+    }
+    return RT_OK;
+}
+
+constexpr size_t DEFAULT_MAX_PATHS = 16u << 20;
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_last_error.c_str(); }
+
+int rt_context_create(int device_id, rt_context** out) {
+    if (!out) return fail(RT_ERR_INVALID, "rt_context_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n)
+        return fail(RT_ERR_DEVICE, "rt_context_create: no such HIP device " + std::to_string(device_id) +
+                                       " (" + std::to_string(n) + " visible)");
+    std::unique_ptr<rt_context> ctx(new rt_context());
+    ctx->device = device_id;
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    *out = ctx.release();
+    return RT_OK;
+}
+
+void rt_context_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    delete ctx;
+}
+
+void* rt_context_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_context_synchronize(rt_context* ctx) {
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_context_synchronize: NULL context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_scene_create(rt_context* ctx, rt_scene** out) {
+    // ctx may be NULL: the scene is then host-only (it can be committed and its flattened
+    // entries inspected, but nothing can be traced or rendered with it)
+    if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: NULL argument");
+    *out = new rt_scene();
+    (*out)->ctx = ctx;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* scene) {
+    if (!scene) return;
+    if (scene->ctx) {
+        (void)hipSetDevice(scene->ctx->device);
+        (void)hipStreamSynchronize(scene->ctx->stream);
+    }
+    delete scene;
+}
+
+int rt_scene_set_materials(rt_scene* s, const rt_material* mats, size_t n) {
+    if (!s || (!mats && n)) return fail(RT_ERR_INVALID, "rt_scene_set_materials: NULL argument");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    s->mats.assign(mats, mats + n);
+    return RT_OK;
+}
+
+int rt_scene_add_spheres(rt_scene* s, const rt_sphere* sp, size_t n) {
+    if (!s || (!sp && n)) return fail(RT_ERR_INVALID, "rt_scene_add_spheres: NULL argument");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    for (size_t i = 0; i < n; i++) {
+        SceneObject o;
+        o.is_mesh = false;
+        o.sphere = sp[i];
+        s->objects.push_back(std::move(o));
+    }
+    return RT_OK;
+}
+
+int rt_scene_add_mesh(rt_scene* s, const rt_triangle* tris, size_t n, const float* xform) {
+    if (!s || (!tris && n)) return fail(RT_ERR_INVALID, "rt_scene_add_mesh: NULL argument");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (xform) {
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (std::memcmp(xform, ident, sizeof(ident)) != 0)
+            return fail(RT_ERR_UNSUPPORTED, "rt_scene_add_mesh: only the identity transform is supported");
+    }
+    SceneObject o;
+    o.is_mesh = true;
+    o.tris.assign(tris, tris + n);
+    s->objects.push_back(std::move(o));
+    return RT_OK;
+}
+
+int rt_scene_set_root(rt_scene* s, int root_kind) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_root: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (root_kind < RT_ROOT_BVH || root_kind > RT_ROOT_LIST) return fail(RT_ERR_INVALID, "unknown root kind");
+    s->root_kind = root_kind;
+    return RT_OK;
+}
+
+int rt_scene_commit(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->flat);
+    if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
+    rt_context* ctx = s->ctx;
+    s->dev.n_entries = (uint32_t)s->flat.n_entries();
+    s->dev.n_prims = (uint32_t)s->flat.n_prims();
+    if (!ctx) {                                // host-only scene: keep the flattened arrays
+        s->committed = true;
+        return RT_OK;
+    }
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const FlatScene& f = s->flat;
+    auto upload = [&](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    };
+    HIP_TRY(upload(s->d_entries, f.entries.data(), f.entries.size() * 4));
+    HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
+    HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
+    HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    s->dev.entries = s->d_entries.p;
+    s->dev.prim_geo = s->d_geo.p;
+    s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
+    s->dev.materials = s->d_mats.p;
+    s->dev.n_entries = (uint32_t)f.n_entries();
+    s->dev.n_prims = (uint32_t)f.n_prims();
+    s->dev.n_mats = (uint32_t)s->mats.size();
+    s->dev.kinds_present = f.kinds_present;
+    // the host copies of the geometry are no longer needed
+    for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
+    s->flat.entries.clear(); s->flat.entries.shrink_to_fit();
+    s->flat.prim_geo.clear(); s->flat.prim_geo.shrink_to_fit();
+    s->committed = true;
+    return RT_OK;
+}
+
+size_t rt_scene_num_prims(const rt_scene* s) { return s ? s->dev.n_prims : 0; }
+size_t rt_scene_num_entries(const rt_scene* s) { return s ? s->dev.n_entries : 0; }
+
+int rt_scene_get_entries(const rt_scene* s, float* out, size_t n_floats) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_entries: NULL argument");
+    if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_entries needs a committed host-only scene");
+    if (n_floats != s->flat.entries.size()) return fail(RT_ERR_INVALID, "rt_scene_get_entries: size mismatch");
+    std::memcpy(out, s->flat.entries.data(), n_floats * sizeof(float));
+    return RT_OK;
+}
+
+int rt_trace_device(rt_scene* s, const void* d_rays, size_t n, float t_min, float t_max, void* d_hits,
+                    uint64_t* counts) {
+    if (!s || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "rt_trace_device: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (counts) {
+        HIP_TRY(ctx->totals.ensure(sizeof(Totals)));
+        HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), ctx->stream));
+    }
+    if (launch_trace_api(ctx->cfg(), s->dev, d_rays, n, t_min, t_max, d_hits, (Totals*)ctx->totals.p,
+                         counts != nullptr))
+        return fail(RT_ERR_DEVICE, "rt_trace_device: kernel launch failed");
+    if (counts) {
+        Totals t;
+        HIP_TRY(hipMemcpyAsync(&t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        counts[0] = t.box; counts[1] = t.tri; counts[2] = t.sph;
+    } else {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return RT_OK;
+}
+
+int rt_trace(rt_scene* s, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out) {
+    if (!s || (n && (!rays || !out))) return fail(RT_ERR_INVALID, "rt_trace: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    if (n == 0) return RT_OK;
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    HIP_TRY(ctx->scratch_in.ensure(n * sizeof(rt_ray)));
+    HIP_TRY(ctx->scratch_out.ensure(n * sizeof(rt_hit)));
+    HIP_TRY(hipMemcpyAsync(ctx->scratch_in.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, ctx->stream));
+    rc = rt_trace_device(s, ctx->scratch_in.p, n, t_min, t_max, ctx->scratch_out.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, ctx->scratch_out.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* p, void* d_accum,
+                     rt_stats* stats) {
+    if (!s || !cam || !p || !d_accum) return fail(RT_ERR_INVALID, "rt_render_device: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    if (p->width < 2 || p->height < 2) return fail(RT_ERR_INVALID, "width and height must be at least 2");
+    if (p->x0 >= p->x1 || p->y0 >= p->y1 || p->x1 > p->width || p->y1 > p->height)
+        return fail(RT_ERR_INVALID, "bad pixel rectangle");
+    if (p->sample_begin >= p->sample_end) return fail(RT_ERR_INVALID, "empty sample range");
+    if (p->max_bounces < 1 || p->max_bounces > MAX_DEPTH)
+        return fail(RT_ERR_INVALID, "max_bounces must be in [1, " + std::to_string(MAX_DEPTH) + "]");
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+
+    const bool profile = (p->flags & RT_RENDER_PROFILE) != 0;
+    const bool count = (p->flags & RT_RENDER_COUNT_VISITS) != 0;
+    const uint32_t rw = p->x1 - p->x0, rh = p->y1 - p->y0;
+    const uint32_t tiles_x = (rw + 7) / 8, tiles_y = (rh + 7) / 8;
+    const size_t n_tiles = (size_t)tiles_x * tiles_y;
+    const uint32_t n_samples = p->sample_end - p->sample_begin;
+    size_t max_paths = p->max_paths_in_flight ? p->max_paths_in_flight : DEFAULT_MAX_PATHS;
+    if (max_paths < 64) max_paths = 64;
+    // batch = (a run of whole tiles) x (a run of samples)
+    const size_t tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
+    const uint32_t samples_per_batch =
+        (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
+    rc = ensure_capacity(ctx, tiles_per_batch * 64 * samples_per_batch);
+    if (rc) return rc;
+
+    RenderBuffers rb;
+    rb.hits = ctx->hits.p;
+    for (int k = 0; k < 3; k++) rb.queue[k] = (uint32_t*)ctx->queue[k].p;
+    rb.Lbuf = ctx->lbuf.p;
+    rb.ctl = (BatchCtl*)ctx->ctl.p;
+    rb.totals = (Totals*)ctx->totals.p;
+    rb.capacity = ctx->capacity;
+    const LaunchCfg cfg = ctx->cfg();
+    hipStream_t st = ctx->stream;
+
+    size_t ev_used = 0;
+    struct Span { size_t e0, e1; int what; };
+    std::vector<Span> spans;
+    double ms_by_kind[2] = {0.0, 0.0};
+    auto fold_spans = [&]() -> int {           // needs the stream to be idle
+        for (const Span& sp : spans) {
+            float m = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&m, ctx->events[sp.e0], ctx->events[sp.e1]));
+            ms_by_kind[sp.what] += m;
+        }
+        spans.clear();
+        ev_used = 0;
+        return RT_OK;
+    };
+    auto mark = [&](int what, auto&& launch) -> int {
+        if (!profile) return launch();
+        int r = get_events(ctx, ev_used + 2);
+        if (r) return r;
+        if (hipEventRecord(ctx->events[ev_used], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
+        int lr = launch();
+        if (hipEventRecord(ctx->events[ev_used + 1], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
+        spans.push_back(Span{ev_used, ev_used + 1, what});
+        ev_used += 2;
+        return lr;
+    };
+
+    HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), st));
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    HIP_TRY(hipEventCreate(&ev_begin));
+    HIP_TRY(hipEventCreate(&ev_end));
+    HIP_TRY(hipEventRecord(ev_begin, st));
+
+    uint64_t trace_launches = 0;
+    int cur = 0;
+    for (size_t tile0 = 0; tile0 < n_tiles; tile0 += tiles_per_batch) {
+        const size_t nt = std::min(tiles_per_batch, n_tiles - tile0);
+        for (uint32_t s0 = 0; s0 < n_samples; s0 += samples_per_batch) {
+            BatchGeom g;
+            g.width = p->width; g.height = p->height;
+            g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
+            g.tiles_x = tiles_x;
+            g.tile_base = (uint32_t)tile0;
+            g.n_pix_slots = (uint32_t)(nt * 64);
+            g.sample_base = p->sample_begin + s0;
+            g.n_samples = std::min(samples_per_batch, n_samples - s0);
+            g.padded = (rw % 8 != 0 || rh % 8 != 0) ? 1u : 0u;
+            const uint32_t n_upper = g.n_pix_slots * g.n_samples;
+
+            HIP_TRY(hipMemsetAsync(ctx->ctl.p, 0, sizeof(BatchCtl), st));
+            auto bind = [&]() {
+                rb.cur = RayBuffers{ctx->rayA[cur].p, ctx->rayB[cur].p, ctx->rayC[cur].p};
+                rb.next = RayBuffers{ctx->rayA[cur ^ 1].p, ctx->rayB[cur ^ 1].p, ctx->rayC[cur ^ 1].p};
+            };
+            bind();
+            if (launch_raygen(cfg, *cam, g, p->seed, rb)) return fail(RT_ERR_DEVICE, "raygen launch failed");
+            for (uint32_t d = 0; d < p->max_bounces; d++) {
+                const bool last = d + 1 == p->max_bounces;
+                int lr = mark(0, [&]() {
+                    return launch_trace(cfg, s->dev, rb, d, last, n_upper, p->t_min, p->sky_intensity, count);
+                });
+                if (lr) return fail(RT_ERR_DEVICE, "trace launch failed");
+                trace_launches++;
+                if (last) break;
+                lr = mark(1, [&]() {
+                    for (uint32_t k = 0; k < 3; k++)
+                        if (s->dev.kinds_present & (1u << k))
+                            if (launch_shade(cfg, s->dev, rb, d, k, n_upper)) return -1;
+                    return 0;
+                });
+                if (lr) return fail(RT_ERR_DEVICE, "shade launch failed");
+                cur ^= 1;
+                bind();
+            }
+            if (launch_accumulate(cfg, g, rb, d_accum, p->max_bounces))
+                return fail(RT_ERR_DEVICE, "accumulate launch failed");
+            if (profile && ev_used > 4096) {
+                // keep the event pool bounded on long renders: fold what has finished so far
+                HIP_TRY(hipStreamSynchronize(st));
+                rc = fold_spans();
+                if (rc) return rc;
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(ev_end, st));
+
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        Totals t;
+        HIP_TRY(hipMemcpyAsync(&t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
+        stats->ms_render = ms;
+        stats->rays_traced = t.rays;
+        stats->paths = (uint64_t)rw * rh * n_samples;
+        stats->box_tests = t.box; stats->tri_tests = t.tri; stats->sph_tests = t.sph;
+        stats->trace_launches = trace_launches;
+        rc = fold_spans();
+        if (rc) return rc;
+        stats->ms_trace = ms_by_kind[0];
+        stats->ms_shade = ms_by_kind[1];
+    }
+    (void)hipEventDestroy(ev_begin);
+    (void)hipEventDestroy(ev_end);
+    return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_render_params* p, float* accum_rgb, rt_stats* stats) {
+    if (!s || !p || !accum_rgb) return fail(RT_ERR_INVALID, "rt_render: NULL argument");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    DeviceBuffer d;
+    HIP_TRY(d.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(d.p, accum_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rt_stats local;
+    rc = rt_render_device(s, cam, p, d.p, stats ? stats : &local);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(accum_rgb, d.p, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_tonemap_device(rt_context* ctx, const void* d_accum, uint32_t spp, void* d_out, size_t npix) {
+    if (!ctx || (npix && (!d_accum || !d_out))) return fail(RT_ERR_INVALID, "rt_tonemap_device: NULL argument");
+    if (spp == 0) return fail(RT_ERR_INVALID, "spp must be positive");
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (launch_tonemap(ctx->cfg(), d_accum, spp, d_out, npix)) return fail(RT_ERR_DEVICE, "tonemap launch failed");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out, size_t npix) {
+    if (!ctx || (npix && (!accum_rgb || !out))) return fail(RT_ERR_INVALID, "rt_tonemap: NULL argument");
+    if (npix == 0) return RT_OK;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    DeviceBuffer in, o;
+    HIP_TRY(in.ensure(npix * 12));
+    HIP_TRY(o.ensure(npix * 4));
+    HIP_TRY(hipMemcpyAsync(in.p, accum_rgb, npix * 12, hipMemcpyHostToDevice, ctx->stream));
+    rc = rt_tonemap_device(ctx, in.p, spp, o.p, npix);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, o.p, npix * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+}  // extern "C"

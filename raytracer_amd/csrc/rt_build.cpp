@@ -1,0 +1,260 @@
+// Host-side scene builder: reproduces the reference's tree TOPOLOGY and box VALUES
+// (Bvh::new shape.rs:94-138, Mesh::build_bvh shape.rs:264-290, compute_aabb shape.rs:218-233)
+// and writes them straight into the pre-order, skip-linked entry array the traversal kernel
+// walks.  Keeping topology and boxes identical is what makes per-ray hits bit-exact: a better
+// tree would test different boxes and turn some of the reference's rounding-induced misses
+// into hits.
+//
+// Built with -ffp-contract=off: box and edge values must be the plain IEEE f32 results.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+#include "rt_internal.hpp"
+
+namespace rtamd {
+namespace {
+
+struct Box { float lo[3], hi[3]; };
+
+// glam's Vec3::min / max are minps / maxps: the second operand when the compare is false
+inline float minps(float a, float b) { return a < b ? a : b; }
+inline float maxps(float a, float b) { return a > b ? a : b; }
+
+inline Box box_infinity() {                    // math.rs:141-146
+    const float inf = std::numeric_limits<float>::infinity();
+    return Box{{inf, inf, inf}, {-inf, -inf, -inf}};
+}
+inline void grow_point(Box& b, const float p[3]) {   // math.rs:174-179
+    for (int k = 0; k < 3; k++) { b.lo[k] = minps(b.lo[k], p[k]); b.hi[k] = maxps(b.hi[k], p[k]); }
+}
+inline Box surrounding(const Box& a, const Box& b) { // math.rs:167-172 (self = a)
+    Box r;
+    for (int k = 0; k < 3; k++) { r.lo[k] = minps(a.lo[k], b.lo[k]); r.hi[k] = maxps(a.hi[k], b.hi[k]); }
+    return r;
+}
+inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+struct Builder {
+    const std::vector<rt_material>& mats;
+    std::vector<SceneObject>& objects;
+    FlatScene& out;
+    std::vector<Box> obj_box;                  // Hittable::get_aabb() per object
+    // scratch for the mesh currently being emitted
+    const SceneObject* mesh = nullptr;
+    std::vector<float> tri_min;                // Triangle::get_aabb().min per triangle (3 floats)
+
+    Builder(const std::vector<rt_material>& m, std::vector<SceneObject>& o, FlatScene& f)
+        : mats(m), objects(o), out(f) {}
+
+    uint32_t matkind(uint32_t mat) const { return mat | (mats[mat].kind << KIND_SHIFT); }
+
+    size_t push_entry() {
+        size_t i = out.n_entries();
+        out.entries.resize(out.entries.size() + 12, 0.0f);
+        return i;
+    }
+    float* entry(size_t i) { return &out.entries[i * 12]; }
+
+    size_t push_box(const Box& b) {
+        size_t i = push_entry();
+        float* e = entry(i);
+        e[0] = b.lo[0]; e[1] = b.lo[1]; e[2] = b.lo[2];
+        e[4] = b.hi[0]; e[5] = b.hi[1]; e[6] = b.hi[2];
+        return i;
+    }
+    void close_box(size_t i) {                 // the skip link: first entry after the subtree
+        entry(i)[3] = u2f((TAG_BOX << TAG_SHIFT) | (uint32_t)out.n_entries());
+    }
+
+    void push_sphere(const SceneObject& o) {
+        float* e = entry(push_entry());
+        e[0] = o.sphere.c[0]; e[1] = o.sphere.c[1]; e[2] = o.sphere.c[2];
+        e[3] = u2f(TAG_SPH << TAG_SHIFT);
+        e[4] = o.sphere.r;
+        e[5] = u2f(matkind(o.sphere.mat));
+        e[7] = u2f(o.prim_base);
+    }
+    void push_triangle(uint32_t local) {
+        const rt_triangle& t = mesh->tris[local];
+        float* e = entry(push_entry());
+        for (int k = 0; k < 3; k++) {
+            e[k] = t.p[0][k];
+            e[4 + k] = t.p[1][k] - t.p[0][k];  // v0v1, shape.rs:417
+            e[8 + k] = t.p[2][k] - t.p[0][k];  // v0v2, shape.rs:418
+        }
+        e[3] = u2f(TAG_TRI << TAG_SHIFT);
+        e[7] = u2f(mesh->prim_base + local);
+        e[11] = u2f(matkind(t.mat));
+    }
+
+    // compute_aabb (shape.rs:218-233): tight box of the triangles, then +-0.0001 on every face
+    Box padded_box(const uint32_t* idx, size_t n) const {
+        Box b = box_infinity();
+        for (size_t i = 0; i < n; i++) {
+            const rt_triangle& t = mesh->tris[idx[i]];
+            grow_point(b, t.p[0]); grow_point(b, t.p[1]); grow_point(b, t.p[2]);
+        }
+        for (int k = 0; k < 3; k++) b.hi[k] += 0.0001f;
+        for (int k = 0; k < 3; k++) b.lo[k] -= 0.0001f;
+        return b;
+    }
+
+    // Mesh::build_bvh (shape.rs:264-290) on idx[0..n), emitting in pre-order
+    void emit_mesh_range(uint32_t* idx, size_t n, int axis) {
+        if (n == 0) return;                    // MeshBvhNode::None never hits
+        if (n == 1) { push_triangle(idx[0]); return; }
+        if (n == 2) {
+            size_t b = push_box(padded_box(idx, 2));
+            push_triangle(idx[1]);             // left = pop() = last
+            push_triangle(idx[0]);             // right = pop() = first
+            close_box(b);
+            return;
+        }
+        const float* key = tri_min.data();
+        std::stable_sort(idx, idx + n, [key, axis](uint32_t a, uint32_t b) {
+            return key[a * 3 + axis] < key[b * 3 + axis];
+        });
+        size_t bx = push_box(padded_box(idx, n));
+        size_t half = n / 2;                   // split_off(len / 2)
+        emit_mesh_range(idx, half, (axis + 1) % 3);
+        emit_mesh_range(idx + half, n - half, (axis + 1) % 3);
+        close_box(bx);
+    }
+
+    void emit_object(uint32_t oi) {
+        const SceneObject& o = objects[oi];
+        if (!o.is_mesh) { push_sphere(o); return; }
+        mesh = &o;
+        size_t n = o.tris.size();
+        tri_min.resize(n * 3);
+        for (size_t i = 0; i < n; i++) {       // Triangle::get_aabb().min, shape.rs:195-199
+            Box b{{o.tris[i].p[0][0], o.tris[i].p[0][1], o.tris[i].p[0][2]},
+                  {o.tris[i].p[0][0], o.tris[i].p[0][1], o.tris[i].p[0][2]}};
+            grow_point(b, o.tris[i].p[1]); grow_point(b, o.tris[i].p[2]);
+            tri_min[i * 3] = b.lo[0]; tri_min[i * 3 + 1] = b.lo[1]; tri_min[i * 3 + 2] = b.lo[2];
+        }
+        std::vector<uint32_t> idx(n);
+        std::iota(idx.begin(), idx.end(), 0u);
+        out.entries.reserve(out.entries.size() + (2 * n + 1) * 12);
+        emit_mesh_range(idx.data(), n, 0);     // Mesh::hit enters at the root node (shape.rs:455)
+        mesh = nullptr;
+    }
+
+    // Bvh::new (shape.rs:94-138) on ids[0..n); returns the node's aabb
+    Box emit_bvh(uint32_t* ids, size_t n, int axis) {
+        if (n == 0) {
+            Box z{{0, 0, 0}, {0, 0, 0}};
+            close_box(push_box(z));
+            return z;
+        }
+        if (n == 1) {
+            Box b = obj_box[ids[0]];
+            size_t bx = push_box(b);
+            emit_object(ids[0]);
+            close_box(bx);
+            return b;
+        }
+        if (n == 2) {
+            uint32_t left = ids[1], right = ids[0];    // pop(), pop()
+            Box b = surrounding(obj_box[left], obj_box[right]);
+            size_t bx = push_box(b);
+            emit_object(left);
+            emit_object(right);
+            close_box(bx);
+            return b;
+        }
+        const std::vector<Box>& ob = obj_box;
+        std::stable_sort(ids, ids + n, [&ob, axis](uint32_t a, uint32_t b) {
+            return ob[a].lo[axis] < ob[b].lo[axis];
+        });
+        size_t half = n / 2;
+        size_t bx = push_box(Box{});           // box is known only after both children exist
+        Box l = emit_bvh(ids, half, (axis + 1) % 3);
+        Box r = emit_bvh(ids + half, n - half, (axis + 1) % 3);
+        Box b = surrounding(l, r);
+        float* e = entry(bx);
+        e[0] = b.lo[0]; e[1] = b.lo[1]; e[2] = b.lo[2];
+        e[4] = b.hi[0]; e[5] = b.hi[1]; e[6] = b.hi[2];
+        close_box(bx);
+        return b;
+    }
+};
+
+}  // namespace
+
+std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
+                             int root_kind, FlatScene& out) {
+    out = FlatScene();
+    if (mats.empty()) return "no materials set";
+    if (mats.size() > MAT_MASK) return "too many materials";
+    for (const rt_material& m : mats)
+        if (m.kind > RT_MAT_EMISSIVE) return "unknown material kind";
+
+    // primitive ids, per-primitive shading data, per-object boxes
+    Builder b(mats, objects, out);
+    uint64_t prim = 0;
+    for (SceneObject& o : objects) {
+        o.prim_base = (uint32_t)prim;
+        prim += o.is_mesh ? o.tris.size() : 1;
+    }
+    if (prim > PRIM_ID_MASK) return "too many primitives";
+    out.prim_geo.resize(prim * 4, 0.0f);
+    out.prim_meta.resize(prim, 0);
+    b.obj_box.resize(objects.size());
+    for (size_t oi = 0; oi < objects.size(); oi++) {
+        SceneObject& o = objects[oi];
+        if (!o.is_mesh) {
+            if (o.sphere.mat >= mats.size()) return "sphere material index out of range";
+            float* g = &out.prim_geo[(size_t)o.prim_base * 4];
+            g[0] = o.sphere.c[0]; g[1] = o.sphere.c[1]; g[2] = o.sphere.c[2]; g[3] = o.sphere.r;
+            out.prim_meta[o.prim_base] = o.sphere.mat | META_SPHERE;
+            out.kinds_present |= 1u << mats[o.sphere.mat].kind;
+            Box bx;                            // Sphere::get_aabb, shape.rs:47-52
+            for (int k = 0; k < 3; k++) { bx.lo[k] = o.sphere.c[k] - o.sphere.r; bx.hi[k] = o.sphere.c[k] + o.sphere.r; }
+            b.obj_box[oi] = bx;
+        } else {
+            Box bx = box_infinity();           // Mesh.aabb: unpadded, shape.rs:241-245
+            for (size_t i = 0; i < o.tris.size(); i++) {
+                const rt_triangle& t = o.tris[i];
+                if (t.mat >= mats.size()) return "triangle material index out of range";
+                grow_point(bx, t.p[0]); grow_point(bx, t.p[1]); grow_point(bx, t.p[2]);
+                // shape.rs:306: normalize(+-v1.n) = +-(v1.n / |v1.n|); glam: v / sqrt((x*x+y*y)+z*z)
+                float len = std::sqrt((t.n0[0] * t.n0[0] + t.n0[1] * t.n0[1]) + t.n0[2] * t.n0[2]);
+                float* g = &out.prim_geo[((size_t)o.prim_base + i) * 4];
+                g[0] = t.n0[0] / len; g[1] = t.n0[1] / len; g[2] = t.n0[2] / len; g[3] = 0.0f;
+                out.prim_meta[o.prim_base + i] = t.mat;
+                out.kinds_present |= 1u << mats[t.mat].kind;
+            }
+            b.obj_box[oi] = bx;
+        }
+    }
+    out.materials.resize(mats.size() * 8, 0.0f);
+    for (size_t i = 0; i < mats.size(); i++) {
+        float* m = &out.materials[i * 8];
+        m[0] = mats[i].rgb[0]; m[1] = mats[i].rgb[1]; m[2] = mats[i].rgb[2]; m[3] = mats[i].param;
+        m[4] = u2f(mats[i].kind); m[5] = u2f(mats[i].flags);
+    }
+
+    std::vector<uint32_t> ids(objects.size());
+    std::iota(ids.begin(), ids.end(), 0u);
+    if (root_kind == RT_ROOT_SINGLE) {
+        if (objects.size() != 1) return "RT_ROOT_SINGLE needs exactly one object";
+        b.emit_object(0);
+    } else if (root_kind == RT_ROOT_LIST) {
+        // HittableList::hit (shape.rs:60-74): every object in order, t_max = closest so far
+        for (uint32_t oi : ids) b.emit_object(oi);
+    } else if (root_kind == RT_ROOT_BVH) {
+        b.emit_bvh(ids.data(), ids.size(), 0);
+    } else {
+        return "unknown root kind";
+    }
+    if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
+    return std::string();
+}
+
+}  // namespace rtamd

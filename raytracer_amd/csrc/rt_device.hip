@@ -1,0 +1,570 @@
+// HIP kernels of the wavefront path tracer (gfx950, wave64).
+//
+// Stages per batch of paths:  raygen -> [ trace -> shade(lambert|metal|dielectric) ] x depth
+//                             -> accumulate.
+// trace   : closest hit over the flattened pre-order entry array; terminates paths that miss
+//           (sky), hit an emitter or reach the depth cap; queues the rest by material kind.
+// shade   : one launch per material kind over that kind's queue (material-sorted, so a wave
+//           runs one scatter routine); surviving rays are compacted into the next ray buffer
+//           with a wave ballot + lane prefix + one atomic per wave.
+//
+// Intersection arithmetic must equal the reference's IEEE f32 results bit for bit, so this file
+// is built with -ffp-contract=off (no FMA), and relies on hipcc's default correctly rounded
+// f32 divide / sqrt and on f32 denormals being preserved.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_internal.hpp"
+
+namespace rtamd {
+
+#define RT_BLOCK 256
+
+struct Counts { uint32_t box, tri, sph; };
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// glam dot: three products, (x + y) + z  (no contraction in this file)
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Closest hit.  Restates Bvh::hit (shape.rs:142-158), Mesh::bvh_hit (shape.rs:292-324),
+// Aabb::hit (math.rs:149-165), ray_triangle_intersection (shape.rs:411-450) and Sphere::hit
+// (shape.rs:19-45) over the pre-order entry array.  best_t starts at the caller's t_max and is
+// the reference's narrowed t_max at every visit.
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, float ox,
+                                            float oy, float oz, float dx, float dy, float dz,
+                                            float t_min, float& best_t, uint32_t& best_prim,
+                                            uint32_t& best_mk, Counts& cnt) {
+    // math.rs:152: inv_d = 1.0 / ray_dir[axis]; the same value at every box, so hoisted
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float EPS = 1.1920929e-7f;           // f32::EPSILON
+    best_prim = RT_MISS;
+    best_mk = 0;
+    uint32_t i = 0;
+    while (i < n_ent) {
+        const float4 a = ent[3 * i];
+        const float4 b = ent[3 * i + 1];
+        const uint32_t w = f2u(a.w);
+        const uint32_t tag = w >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            if (COUNT) cnt.box++;
+            // math.rs:153-162.  The per-axis early return is equivalent to one test after the
+            // third axis: t_min only grows and t_max only shrinks.
+            float t0 = (a.x - ox) * ix, t1 = (b.x - ox) * ix;
+            float lo = ix < 0.0f ? t1 : t0, hi = ix < 0.0f ? t0 : t1;
+            float tmn = lo > t_min ? lo : t_min;
+            float tmx = hi < best_t ? hi : best_t;
+            bool miss = tmx <= tmn;
+            t0 = (a.y - oy) * iy; t1 = (b.y - oy) * iy;
+            lo = iy < 0.0f ? t1 : t0; hi = iy < 0.0f ? t0 : t1;
+            tmn = lo > tmn ? lo : tmn;
+            tmx = hi < tmx ? hi : tmx;
+            miss = miss || (tmx <= tmn);
+            t0 = (a.z - oz) * iz; t1 = (b.z - oz) * iz;
+            lo = iz < 0.0f ? t1 : t0; hi = iz < 0.0f ? t0 : t1;
+            tmn = lo > tmn ? lo : tmn;
+            tmx = hi < tmx ? hi : tmx;
+            miss = miss || (tmx <= tmn);
+            i = miss ? (w & SKIP_MASK) : i + 1;
+        } else if (tag == TAG_TRI) {
+            if (COUNT) cnt.tri++;
+            const float4 c = ent[3 * i + 2];
+            // a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2
+            const float px = dy * c.z - dz * c.y;          // pvec = dir x v0v2
+            const float py = dz * c.x - dx * c.z;
+            const float pz = dx * c.y - dy * c.x;
+            const float det = dot3(b.x, b.y, b.z, px, py, pz);
+            if (!(fabsf(det) < EPS)) {
+                const float inv_det = 1.0f / det;
+                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+                const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+                if (!(u < 0.0f || u > 1.0f)) {
+                    const float qx = ty * b.z - tz * b.y;  // qvec = tvec x v0v1
+                    const float qy = tz * b.x - tx * b.z;
+                    const float qz = tx * b.y - ty * b.x;
+                    const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                    if (!(v < 0.0f || u + v > 1.0f)) {
+                        const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
+                        if (t >= t_min && t < best_t) {    // shape.rs:297
+                            best_t = t;
+                            best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
+                            best_mk = f2u(c.w);
+                        }
+                    }
+                }
+            }
+            i = i + 1;
+        } else {
+            if (COUNT) cnt.sph++;
+            // a.xyz = centre, b.x = radius
+            const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
+            const float qa = dot3(dx, dy, dz, dx, dy, dz);
+            const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
+            const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
+            const float disc = half_b * half_b - qa * qc;
+            if (!(disc < 0.0f)) {
+                const float sqrtd = sqrtf(disc);
+                float root = (-half_b - sqrtd) / qa;
+                bool ok = true;
+                if (root < t_min || best_t < root) {       // shape.rs:32-36, closed interval
+                    root = (-half_b + sqrtd) / qa;
+                    if (root < t_min || best_t < root) ok = false;
+                }
+                if (ok) {
+                    best_t = root;
+                    best_prim = f2u(b.w);
+                    best_mk = f2u(b.y);
+                }
+            }
+            i = i + 1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rt_trace: AoS rays in, full hit records out (the hit-parity surface)
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
+            rt_hit* __restrict__ out, Totals* totals) {
+    const float4* ent = (const float4*)sc.entries;
+    const float4* geo = (const float4*)sc.prim_geo;
+    Counts cnt{0, 0, 0};
+    for (size_t r = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (size_t)gridDim.x * RT_BLOCK) {
+        const float ox = rays[r * 6 + 0], oy = rays[r * 6 + 1], oz = rays[r * 6 + 2];
+        const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+        float t = t_max;
+        uint32_t prim, mk;
+        closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
+        rt_hit h;
+        if (prim == RT_MISS) {
+            h.t = 0.0f; h.prim_id = RT_MISS;
+            h.p[0] = h.p[1] = h.p[2] = 0.0f; h.n[0] = h.n[1] = h.n[2] = 0.0f;
+            h.front_face = 0; h.mat = 0;
+        } else {
+            const uint32_t id = prim & PRIM_ID_MASK;
+            const float4 g = geo[id];
+            const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
+            float nx, ny, nz;
+            if (sc.prim_meta[id] & META_SPHERE) {          // shape.rs:41
+                nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
+            } else {                                       // shape.rs:298-307
+                const bool bf = (prim & PRIM_BACKFACE) != 0;
+                nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
+            }
+            const bool front = dot3(dx, dy, dz, nx, ny, nz) < 0.0f;   // camera.rs:112-119
+            h.t = t; h.prim_id = id;
+            h.p[0] = px; h.p[1] = py; h.p[2] = pz;
+            h.n[0] = front ? nx : -nx; h.n[1] = front ? ny : -ny; h.n[2] = front ? nz : -nz;
+            h.front_face = front ? 1u : 0u;
+            h.mat = mk & MAT_MASK;
+        }
+        out[r] = h;
+    }
+    if (COUNT) {
+        atomicAdd(&totals->box, (unsigned long long)cnt.box);
+        atomicAdd(&totals->tri, (unsigned long long)cnt.tri);
+        atomicAdd(&totals->sph, (unsigned long long)cnt.sph);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave-level compaction: ballot + lane prefix + one atomic per wave
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0u;
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based RNG: a 64-bit key per (pixel, sample) made by raygen, then
+// value = hash(key, counter) with counter = depth * 16 + dimension
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pcg(uint32_t v) {
+    const uint32_t s = v * 747796405u + 2891336453u;
+    const uint32_t w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+    return (w >> 22u) ^ w;
+}
+__device__ __forceinline__ uint32_t rng_u32(uint32_t klo, uint32_t khi, uint32_t ctr) {
+    return pcg(pcg(klo + ctr * 0x9E3779B9u) ^ khi);
+}
+// uniform in [0,1)
+__device__ __forceinline__ float rng_f01(uint32_t klo, uint32_t khi, uint32_t ctr) {
+    return (float)(rng_u32(klo, khi, ctr) >> 8) * 5.9604645e-8f;
+}
+constexpr uint32_t RNG_CTR_CAMERA = 0xFFFF0000u;
+
+// uniform on the unit sphere: the distribution of RandomSeries::random_on_unit_sphere
+// (math.rs:78-80) without its rejection loop
+__device__ __forceinline__ void sample_sphere(float u1, float u2, float& x, float& y, float& z) {
+    z = 1.0f - 2.0f * u1;
+    const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    x = r * __builtin_amdgcn_cosf(u2);         // cos(2*pi*u2): the hardware takes revolutions
+    y = r * __builtin_amdgcn_sinf(u2);
+}
+// uniform in the unit ball: the distribution of random_in_unit_sphere (math.rs:69-76)
+__device__ __forceinline__ void sample_ball(float u1, float u2, float u3, float& x, float& y, float& z) {
+    sample_sphere(u1, u2, x, y, z);
+    const float s = cbrtf(u3);
+    x *= s; y *= s; z *= s;
+}
+
+// decode a pixel slot of the batch (8x8 tiles, row-major inside a tile)
+__device__ __forceinline__ bool slot_pixel(const BatchGeom& g, uint32_t q, uint32_t& x, uint32_t& y) {
+    const uint32_t tile = g.tile_base + (q >> 6), in = q & 63u;
+    const uint32_t tx = tile % g.tiles_x, ty = tile / g.tiles_x;
+    x = g.x0 + tx * 8u + (in & 7u);
+    y = g.y0 + ty * 8u + (in >> 3);
+    return x < g.x1 && y < g.y1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// raygen: the per-sample head of the tile loop (main.rs:362-364) + Camera::get_ray
+// (camera.rs:80-89).  Path slot = sample_in_batch * n_pix_slots + pixel_slot.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK)
+k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
+         float4* __restrict__ B, float4* __restrict__ C, BatchCtl* ctl) {
+    const uint32_t total = g.n_pix_slots * g.n_samples;
+    const float inv_w = 1.0f / (float)(g.width - 1u);      // main.rs:330-331
+    const float inv_h = 1.0f / (float)(g.height - 1u);
+    // trip count is uniform per wave so that every lane reaches the ballot in wave_append
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < total; base += gridDim.x * RT_BLOCK) {
+        const uint32_t s = base + threadIdx.x;
+        bool valid = s < total;
+        uint32_t x = 0, y = 0;
+        const uint32_t k = s / g.n_pix_slots, q = s - k * g.n_pix_slots;
+        valid = valid && slot_pixel(g, q, x, y);
+        float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+        if (valid) {
+            const uint32_t pix = y * g.width + x, smp = g.sample_base + k;
+            const uint32_t klo = pcg(pix ^ pcg(smp ^ pcg(seed_lo)));
+            const uint32_t khi = pcg(smp + pcg(pix + pcg(seed_hi ^ 0x85EBCA6Bu)));
+            const float u = ((float)x + rng_f01(klo, khi, RNG_CTR_CAMERA + 0u)) * inv_w;
+            const float v = ((float)y + rng_f01(klo, khi, RNG_CTR_CAMERA + 1u)) * inv_h;
+            const float sx = u, sy = 1.0f - v;
+            float offx = 0.0f, offy = 0.0f, offz = 0.0f;
+            if (cam.lens_radius != 0.0f) {                 // uniform disk (math.rs:60-67)
+                const float r = cam.lens_radius * sqrtf(rng_f01(klo, khi, RNG_CTR_CAMERA + 2u));
+                const float ph = rng_f01(klo, khi, RNG_CTR_CAMERA + 3u);
+                const float rx = r * __builtin_amdgcn_cosf(ph), ry = r * __builtin_amdgcn_sinf(ph);
+                offx = cam.u[0] * rx + cam.v[0] * ry;
+                offy = cam.u[1] * rx + cam.v[1] * ry;
+                offz = cam.u[2] * rx + cam.v[2] * ry;
+            }
+            a.x = cam.origin[0] + offx; a.y = cam.origin[1] + offy; a.z = cam.origin[2] + offz;
+            a.w = u2f(s);
+            b.x = cam.lower_left[0] + sx * cam.horizontal[0] + sy * cam.vertical[0] - cam.origin[0] - offx;
+            b.y = cam.lower_left[1] + sx * cam.horizontal[1] + sy * cam.vertical[1] - cam.origin[1] - offy;
+            b.z = cam.lower_left[2] + sx * cam.horizontal[2] + sy * cam.vertical[2] - cam.origin[2] - offz;
+            b.w = u2f(klo);
+            c = make_float4(1.0f, 1.0f, 1.0f, u2f(khi));
+        }
+        uint32_t pos = s;
+        if (g.padded) pos = wave_append(valid, &ctl->ray_count[0]);
+        if (valid) { A[pos] = a; B[pos] = b; C[pos] = c; }
+    }
+    if (!g.padded && blockIdx.x == 0 && threadIdx.x == 0) ctl->ray_count[0] = total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace: closest hit for every live ray of this depth, terminate or queue
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_trace(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
+        const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
+        uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf, BatchCtl* ctl,
+        Totals* totals, uint32_t depth, uint32_t last_depth, float t_min, float sky_intensity) {
+    const float4* ent = (const float4*)sc.entries;
+    const float4* mats = (const float4*)sc.materials;
+    const uint32_t n = ctl->ray_count[depth];
+    Counts cnt{0, 0, 0};
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        uint32_t kind = 7u;                                // 7 = nothing to queue
+        if (valid) {
+            const float4 a = A[i], b = B[i];
+            float t = __builtin_inff();                    // main.rs:46: t_max = f32::INFINITY
+            uint32_t prim, mk;
+            closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
+            const uint32_t slot = f2u(a.w);
+            if (prim == RT_MISS) {
+                // sky_color (main.rs:31-38): gradient on the y of the normalised direction
+                const float4 c = C[i];
+                const float len = sqrtf(dot3(b.x, b.y, b.z, b.x, b.y, b.z));
+                const float tt = 0.5f * (b.y / len + 1.0f);
+                const float r = ((1.0f - tt) * 1.0f + tt * 0.5f) * sky_intensity;
+                const float gg = ((1.0f - tt) * 1.0f + tt * 0.7f) * sky_intensity;
+                const float bb = ((1.0f - tt) * 1.0f + tt * 1.0f) * sky_intensity;
+                Lbuf[slot] = make_float4(c.x * r, c.y * gg, c.z * bb, 0.0f);
+            } else {
+                const uint32_t k = mk >> KIND_SHIFT;
+                if (k == RT_MAT_EMISSIVE) {                // emit, no scatter (material.rs:126-130)
+                    const float4 c = C[i];
+                    const float4 m = mats[2 * (mk & MAT_MASK)];
+                    Lbuf[slot] = make_float4(c.x * m.x, c.y * m.y, c.z * m.z, 0.0f);
+                } else if (last_depth) {                   // the next ray_color returns 0 (main.rs:41-43)
+                    Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else {
+                    hits[i] = make_uint2(f2u(t), prim);
+                    kind = k;
+                }
+            }
+        }
+        uint32_t pos;
+        pos = wave_append(kind == 0u, &ctl->qcount[depth][0]);
+        if (kind == 0u) q0[pos] = i;
+        pos = wave_append(kind == 1u, &ctl->qcount[depth][1]);
+        if (kind == 1u) q1[pos] = i;
+        pos = wave_append(kind == 2u, &ctl->qcount[depth][2]);
+        if (kind == 2u) q2[pos] = i;
+    }
+    if (COUNT) {
+        atomicAdd(&totals->box, (unsigned long long)cnt.box);
+        atomicAdd(&totals->tri, (unsigned long long)cnt.tri);
+        atomicAdd(&totals->sph, (unsigned long long)cnt.sph);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: Material::scatter (material.rs) for one kind; compacts survivors into the next buffer
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ void __launch_bounds__(RT_BLOCK)
+k_shade(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
+        const float4* __restrict__ C, const uint2* __restrict__ hits, const uint32_t* __restrict__ queue,
+        float4* __restrict__ nA, float4* __restrict__ nB, float4* __restrict__ nC,
+        float4* __restrict__ Lbuf, BatchCtl* ctl, uint32_t depth) {
+    const float4* geo = (const float4*)sc.prim_geo;
+    const float4* mats = (const float4*)sc.materials;
+    const uint32_t n = ctl->qcount[depth][KIND];
+    const uint32_t ctr = depth * 16u;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        const uint32_t j = base + threadIdx.x;
+        const bool valid = j < n;
+        bool alive = false;
+        float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
+        uint32_t slot = 0;
+        if (valid) {
+            const uint32_t i = queue[j];
+            const float4 a = A[i], b = B[i], c = C[i];
+            const uint2 h = hits[i];
+            const float t = u2f(h.x);
+            const uint32_t id = h.y & PRIM_ID_MASK;
+            const uint32_t meta = sc.prim_meta[id];
+            const float4 g = geo[id];
+            const float4 m0 = mats[2 * (meta & MAT_MASK)];
+            const uint32_t klo = f2u(b.w), khi = f2u(c.w);
+            slot = f2u(a.w);
+            // hit point and face-forwarded normal
+            const float px = a.x + b.x * t, py = a.y + b.y * t, pz = a.z + b.z * t;
+            float nx, ny, nz;
+            if (meta & META_SPHERE) {
+                nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
+            } else {
+                const bool bf = (h.y & PRIM_BACKFACE) != 0;
+                nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
+            }
+            const bool front = dot3(b.x, b.y, b.z, nx, ny, nz) < 0.0f;
+            if (!front) { nx = -nx; ny = -ny; nz = -nz; }
+            float ddx, ddy, ddz, ar = m0.x, ag = m0.y, ab = m0.z;
+            if (KIND == RT_MAT_LAMBERT) {                  // material.rs:27-56
+                float sx, sy, sz;
+                sample_sphere(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), sx, sy, sz);
+                float ex = nx + sx, ey = ny + sy, ez = nz + sz;
+                if (fabsf(ex) + fabsf(ey) + fabsf(ez) < 1.1920929e-7f) { ex = nx; ey = ny; ez = nz; }
+                const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+                ddx = ex / len; ddy = ey / len; ddz = ez / len;
+                const float4 m1 = mats[2 * (meta & MAT_MASK) + 1];
+                if (f2u(m1.y) & RT_MAT_FLAG_NORMAL_SHADING) {
+                    ar = (nx + 1.0f) * 0.5f; ag = (ny + 1.0f) * 0.5f; ab = (nz + 1.0f) * 0.5f;
+                }
+                alive = true;
+            } else if (KIND == RT_MAT_METAL) {             // material.rs:63-80
+                const float dn2 = 2.0f * dot3(b.x, b.y, b.z, nx, ny, nz);
+                const float rx = b.x - dn2 * nx, ry = b.y - dn2 * ny, rz = b.z - dn2 * nz;
+                float sx, sy, sz;
+                sample_ball(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), rng_f01(klo, khi, ctr + 2u),
+                            sx, sy, sz);
+                ddx = rx + m0.w * sx; ddy = ry + m0.w * sy; ddz = rz + m0.w * sz;
+                alive = dot3(rx, ry, rz, nx, ny, nz) > 0.0f;
+            } else {                                       // material.rs:87-120
+                const float ratio = front ? 1.0f / m0.w : m0.w;
+                const float len = sqrtf(dot3(b.x, b.y, b.z, b.x, b.y, b.z));
+                const float ux = b.x / len, uy = b.y / len, uz = b.z / len;
+                const float cos_t = fminf(dot3(-ux, -uy, -uz, nx, ny, nz), 1.0f);
+                const float sin_t = sqrtf(1.0f - cos_t * cos_t);
+                bool refl = ratio * sin_t > 1.0f;
+                if (!refl) {                               // reflectance (math.rs:105-110)
+                    float r0 = (1.0f - ratio) / (1.0f + ratio);
+                    r0 = r0 * r0;
+                    const float om = 1.0f - cos_t;
+                    const float om2 = om * om;
+                    refl = r0 + (1.0f - r0) * (om2 * om2 * om) > rng_f01(klo, khi, ctr);
+                }
+                if (refl) {                                // reflect (math.rs:94-96)
+                    const float dn2 = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
+                    ddx = ux - dn2 * nx; ddy = uy - dn2 * ny; ddz = uz - dn2 * nz;
+                } else {                                   // refract (math.rs:98-103)
+                    const float ppx = ratio * (ux + cos_t * nx), ppy = ratio * (uy + cos_t * ny),
+                                ppz = ratio * (uz + cos_t * nz);
+                    const float par = -sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+                    ddx = ppx + par * nx; ddy = ppy + par * ny; ddz = ppz + par * nz;
+                }
+                alive = true;
+            }
+            na = make_float4(px, py, pz, a.w);
+            nb = make_float4(ddx, ddy, ddz, b.w);
+            nc = make_float4(c.x * ar, c.y * ag, c.z * ab, c.w);
+        }
+        const uint32_t pos = wave_append(alive, &ctl->ray_count[depth + 1]);
+        if (alive) { nA[pos] = na; nB[pos] = nb; nC[pos] = nc; }
+        else if (valid) Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // scatter() == false: emitted only
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulate: per pixel, add the batch's samples in sample order (one owner per pixel: no
+// atomics, fixed summation order).  Thread 0 also folds the batch's ray counts into the totals.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(RT_BLOCK)
+k_accumulate(BatchGeom g, const float4* __restrict__ Lbuf, float* __restrict__ accum, const BatchCtl* ctl,
+             Totals* totals, uint32_t max_bounces) {
+    for (uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x; q < g.n_pix_slots; q += gridDim.x * RT_BLOCK) {
+        uint32_t x, y;
+        if (!slot_pixel(g, q, x, y)) continue;
+        float r = 0.0f, gg = 0.0f, b = 0.0f;
+        for (uint32_t k = 0; k < g.n_samples; k++) {
+            const float4 l = Lbuf[(size_t)k * g.n_pix_slots + q];
+            r += l.x; gg += l.y; b += l.z;
+        }
+        float* dst = accum + ((size_t)y * g.width + x) * 3;
+        dst[0] += r; dst[1] += gg; dst[2] += b;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long rays = 0;
+        for (uint32_t d = 0; d < max_bounces; d++) rays += ctl->ray_count[d];
+        totals->rays += rays;
+    }
+}
+
+// main.rs:369-373 + rgb_to_u32 (math.rs:112-116)
+__device__ __forceinline__ uint32_t sat_u32(float f) {     // Rust `as u32`
+    if (!(f == f) || f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)f;
+}
+__global__ void __launch_bounds__(RT_BLOCK)
+k_tonemap(const float* __restrict__ accum, float scale, uint32_t* __restrict__ out, size_t npix) {
+    for (size_t p = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; p < npix; p += (size_t)gridDim.x * RT_BLOCK) {
+        float c[3];
+        for (int k = 0; k < 3; k++) {
+            const float s = sqrtf(accum[p * 3 + k] * scale);
+            c[k] = s < 1.0f ? s : 1.0f;                    // Vec3::min(sqrt, one): minps
+        }
+        out[p] = (sat_u32(255.999f * c[0]) << 16) | (sat_u32(255.999f * c[1]) << 8) | sat_u32(255.999f * c[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t grid_for(size_t n, uint32_t cap) {
+    size_t b = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (uint32_t)b;
+}
+static inline int check_launch() { return hipGetLastError() == hipSuccess ? 0 : -1; }
+
+int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
+                     float t_max, void* d_hits, Totals* d_counts, bool count) {
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t grid = grid_for(n, cfg.grid_cap);
+    if (count)
+        hipLaunchKernelGGL(k_trace_api<true>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n,
+                           t_min, t_max, (rt_hit*)d_hits, d_counts);
+    else
+        hipLaunchKernelGGL(k_trace_api<false>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n,
+                           t_min, t_max, (rt_hit*)d_hits, d_counts);
+    return check_launch();
+}
+
+int launch_raygen(const LaunchCfg& cfg, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
+                  const RenderBuffers& rb) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const size_t total = (size_t)g.n_pix_slots * g.n_samples;
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, cfg.grid_cap)), dim3(RT_BLOCK), 0, st, cam, g,
+                       (uint32_t)seed, (uint32_t)(seed >> 32), (float4*)rb.cur.A, (float4*)rb.cur.B,
+                       (float4*)rb.cur.C, rb.ctl);
+    return check_launch();
+}
+
+int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const RenderBuffers& rb, uint32_t depth,
+                 bool last_depth, uint32_t n_upper, float t_min, float sky_intensity, bool count) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t grid = grid_for(n_upper, cfg.grid_cap);
+    if (count)
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,
+                           (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
+                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, rb.ctl, rb.totals, depth,
+                           last_depth ? 1u : 0u, t_min, sky_intensity);
+    else
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,
+                           (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
+                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, rb.ctl, rb.totals, depth,
+                           last_depth ? 1u : 0u, t_min, sky_intensity);
+    return check_launch();
+}
+
+int launch_shade(const LaunchCfg& cfg, const DevScene& sc, const RenderBuffers& rb, uint32_t depth,
+                 uint32_t kind, uint32_t n_upper) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t grid = grid_for(n_upper, cfg.grid_cap);
+#define RT_SHADE(K)                                                                                     \
+    hipLaunchKernelGGL(k_shade<K>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,      \
+                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (const uint2*)rb.hits,         \
+                       (const uint32_t*)rb.queue[K], (float4*)rb.next.A, (float4*)rb.next.B,            \
+                       (float4*)rb.next.C, (float4*)rb.Lbuf, rb.ctl, depth)
+    if (kind == RT_MAT_LAMBERT) RT_SHADE(0);
+    else if (kind == RT_MAT_METAL) RT_SHADE(1);
+    else if (kind == RT_MAT_DIELECTRIC) RT_SHADE(2);
+    else return -1;
+#undef RT_SHADE
+    return check_launch();
+}
+
+int launch_accumulate(const LaunchCfg& cfg, const BatchGeom& g, const RenderBuffers& rb, void* d_accum,
+                      uint32_t max_bounces) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(g.n_pix_slots, cfg.grid_cap)), dim3(RT_BLOCK), 0, st, g,
+                       (const float4*)rb.Lbuf, (float*)d_accum, (const BatchCtl*)rb.ctl, rb.totals, max_bounces);
+    return check_launch();
+}
+
+int launch_tonemap(const LaunchCfg& cfg, const void* d_accum, uint32_t spp, void* d_out, size_t npix) {
+    if (npix == 0) return 0;
+    hipStream_t st = (hipStream_t)cfg.stream;
+    hipLaunchKernelGGL(k_tonemap, dim3(grid_for(npix, cfg.grid_cap)), dim3(RT_BLOCK), 0, st,
+                       (const float*)d_accum, 1.0f / (float)spp, (uint32_t*)d_out, npix);
+    return check_launch();
+}
+
+}  // namespace rtamd

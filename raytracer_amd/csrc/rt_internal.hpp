@@ -1,0 +1,133 @@
+// Internal interfaces shared by the host scene builder, the C-ABI glue and the HIP kernels.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_abi.h"
+
+namespace rtamd {
+
+// ---------------------------------------------------------------------------------------------
+// Flattened scene.
+//
+// The closest-hit query of the reference walks its trees left child first and narrows t_max to
+// the closest hit found so far (shape.rs:142-158, 292-324).  That fixed visiting order is a
+// pre-order walk, so the trees are stored as ONE array of entries in pre-order with a skip
+// link per box: visit entry i; a box that is hit continues at i+1 (its left child), a box that
+// is missed continues at its skip link (the entry after its subtree); a primitive continues
+// at i+1.  No stack, and every box test sees exactly the t_max the reference's recursion would.
+//
+// One entry = three float4 (48 bytes):
+//   box      a = (min.xyz , TAG_BOX<<30 | skip)   b = (max.xyz , 0)
+//   triangle a = (v0.xyz  , TAG_TRI<<30)          b = (e1.xyz  , prim_id)   c = (e2.xyz, matkind)
+//   sphere   a = (c.xyz   , TAG_SPH<<30)          b = (r, matkind, 0, prim_id)
+// e1 = v1 - v0 and e2 = v2 - v0 are the reference's v0v1 / v0v2 (shape.rs:417-418) computed
+// once instead of per test; matkind = material index | material kind << 28.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
+constexpr uint32_t TAG_SHIFT = 30;
+constexpr uint32_t SKIP_MASK = (1u << TAG_SHIFT) - 1u;
+constexpr uint32_t KIND_SHIFT = 28;
+constexpr uint32_t MAT_MASK = (1u << KIND_SHIFT) - 1u;
+constexpr uint32_t PRIM_BACKFACE = 1u << 31;       // flag in the compact hit record
+constexpr uint32_t PRIM_ID_MASK = 0x3FFFFFFFu;
+constexpr uint32_t META_SPHERE = 1u << 31;         // flag in prim_meta
+
+struct FlatScene {
+    std::vector<float> entries;        // 12 floats per entry
+    std::vector<float> prim_geo;       // 4 floats per primitive: tri (unit n0, 0) / sphere (c, r)
+    std::vector<uint32_t> prim_meta;   // material index | META_SPHERE
+    std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
+    uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
+    size_t n_entries() const { return entries.size() / 12; }
+    size_t n_prims() const { return prim_meta.size(); }
+};
+
+struct SceneObject {
+    bool is_mesh = false;
+    rt_sphere sphere{};
+    std::vector<rt_triangle> tris;
+    uint32_t prim_base = 0;
+};
+
+// Builds the reference-topology trees and flattens them.  Returns an empty string on success,
+// otherwise the error message.
+std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
+                             int root_kind, FlatScene& out);
+
+// ---------------------------------------------------------------------------------------------
+// Device side
+// ---------------------------------------------------------------------------------------------
+struct DevScene {
+    const void* entries;      // float4[3 * n_entries]
+    const void* prim_geo;     // float4[n_prims]
+    const uint32_t* prim_meta;
+    const void* materials;    // float4[2 * n_mats]
+    uint32_t n_entries;
+    uint32_t n_prims;
+    uint32_t n_mats;
+    uint32_t kinds_present;
+};
+
+constexpr uint32_t MAX_DEPTH = 64;
+
+// Per-batch control block in device memory (zeroed before every batch).
+struct BatchCtl {
+    uint32_t ray_count[MAX_DEPTH + 1];   // live rays entering depth d
+    uint32_t qcount[MAX_DEPTH][4];       // rays queued for the shade kernel of kind k at depth d
+};
+
+// Totals in device memory, read back once per render call.
+struct Totals {
+    unsigned long long rays, box, tri, sph;
+};
+
+// One wavefront batch: pixels [pix_base, pix_base + n_pix_slots) of the rectangle in 8x8-tile
+// order, samples [sample_base, sample_base + n_samples).
+struct BatchGeom {
+    uint32_t width, height;       // full frame
+    uint32_t x0, y0, x1, y1;      // rectangle
+    uint32_t tiles_x;             // 8x8 tiles per row of the rectangle
+    uint32_t tile_base;           // first tile of this batch
+    uint32_t n_pix_slots;         // 64 * tiles in this batch
+    uint32_t sample_base, n_samples;
+    uint32_t padded;              // some slots fall outside the rectangle
+};
+
+struct RayBuffers {
+    void* A;   // float4: origin.xyz, path slot
+    void* B;   // float4: dir.xyz,    rng key low
+    void* C;   // float4: throughput, rng key high
+};
+
+struct RenderBuffers {
+    RayBuffers cur, next;
+    void* hits;            // uint2 per ray: t bits, prim id | PRIM_BACKFACE
+    uint32_t* queue[3];    // ray indices per scattering material kind
+    void* Lbuf;            // float4 per path slot: the path's radiance
+    BatchCtl* ctl;
+    Totals* totals;
+    size_t capacity;       // paths
+};
+
+struct LaunchCfg {
+    void* stream;          // hipStream_t
+    uint32_t grid_cap;     // upper bound on blocks per launch
+};
+
+// kernels' host-side launchers (rt_device.hip)
+int launch_trace_api(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min,
+                     float t_max, void* d_hits, Totals* d_counts, bool count);
+int launch_raygen(const LaunchCfg&, const rt_camera&, const BatchGeom&, uint64_t seed, const RenderBuffers&);
+int launch_trace(const LaunchCfg&, const DevScene&, const RenderBuffers&, uint32_t depth, bool last_depth,
+                 uint32_t n_upper, float t_min, float sky_intensity, bool count);
+int launch_shade(const LaunchCfg&, const DevScene&, const RenderBuffers&, uint32_t depth, uint32_t kind,
+                 uint32_t n_upper);
+int launch_accumulate(const LaunchCfg&, const BatchGeom&, const RenderBuffers&, void* d_accum,
+                      uint32_t max_bounces);
+int launch_tonemap(const LaunchCfg&, const void* d_accum, uint32_t spp, void* d_out, size_t npix);
+
+}  // namespace rtamd

@@ -1,0 +1,110 @@
+"""Image-level parity of the wavefront renderer against the oracle's tile renderer.
+
+The GPU uses a counter-based RNG, so images are compared statistically: the RMSE between the
+GPU image and an oracle image at matched spp must not exceed the RMSE between two oracle images
+rendered with different seeds (the Monte-Carlo noise floor) by more than 15 %, and the image
+means must agree within 2 %.  Bound: RMSE(gpu, oracle) <= 1.15 * RMSE(oracle, oracle')."""
+import numpy as np
+import pytest
+
+from helpers import asset, mirror, product_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def _compare(rt, ob, ctx, osc, w, h, spp, depth, clip=None):
+    sc = mirror(rt, ctx, osc)
+    cam = product_camera(rt, osc, w, h)
+    a, _, st_a = osc.render(w, h, spp, depth, seed_offset=0)
+    b, _, _ = osc.render(w, h, spp, depth, seed_offset=7919)
+    p = rt.Scene.params(w, h, spp, depth, osc.sky)
+    g, st = sc.render(cam, p)
+    a, b, g = a / spp, b / spp, g / spp
+    if clip is not None:                        # tame fireflies so the RMSE is a stable statistic
+        a, b, g = (np.minimum(x, clip) for x in (a, b, g))
+    floor = _rmse(a, b)
+    err = max(_rmse(g, a), _rmse(g, b))
+    mean_o = 0.5 * (a.mean() + b.mean())
+    assert np.isfinite(g).all()
+    assert err <= 1.15 * floor, f"rmse {err:.5f} vs noise floor {floor:.5f}"
+    assert abs(g.mean() - mean_o) <= 0.02 * mean_o, f"mean {g.mean():.5f} vs {mean_o:.5f}"
+    # same estimator => same expected ray count per path
+    assert abs(st["rays_traced"] / st["paths"] - st_a["rays"] / st_a["paths"]) < 0.03
+    assert st["paths"] == w * h * spp
+    return g, a
+
+
+def test_cornell_plane_image(rt, ob, ctx):
+    osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    _compare(rt, ob, ctx, osc, 128, 128, 64, 6, clip=4.0)
+
+
+def test_cornell_full_image_depth8(rt, ob, ctx):
+    osc = ob.Scene.cornell_box(asset("cornell_box.obj"))
+    _compare(rt, ob, ctx, osc, 96, 96, 32, 8, clip=4.0)
+
+
+def test_world1_image(rt, ob, ctx):
+    _compare(rt, ob, ctx, ob.Scene.world1(), 160, 90, 48, 6, clip=4.0)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_world2_image(rt, ob, ctx, variant):
+    _compare(rt, ob, ctx, ob.Scene.world2(asset("thing.obj"), variant), 96, 96, 48, 6, clip=6.0)
+
+
+def test_deterministic_and_partition_invariant(rt, ob, ctx):
+    osc = ob.Scene.world2(asset("thing.obj"), 1)
+    sc = mirror(rt, ctx, osc)
+    w, h, spp, depth = 100, 77, 12, 6          # not multiples of 8: padded tiles
+    cam = product_camera(rt, osc, w, h)
+    full, st = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky))
+    again, st2 = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky))
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))
+    assert st["rays_traced"] == st2["rays_traced"]
+    # pixel rectangles (8-aligned cuts keep the same tiles): bit-identical
+    acc = np.zeros_like(full)
+    total_rays = 0
+    for rect in [(0, 0, 48, 40), (48, 0, 100, 40), (0, 40, 100, 77)]:
+        acc, s = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, rect=rect), accum=acc)
+        total_rays += s["rays_traced"]
+    assert np.array_equal(full.view(np.uint32), acc.view(np.uint32))
+    assert total_rays == st["rays_traced"]
+    # sample ranges: same samples, different summation grouping
+    acc = np.zeros_like(full)
+    for rng_ in [(0, 5), (5, 12)]:
+        acc, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, samples=rng_), accum=acc)
+    np.testing.assert_allclose(acc, full, rtol=2e-5, atol=1e-6)
+    # small batches (many wavefront batches) give the same image as one big batch
+    small, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, max_paths=64 * 40))
+    np.testing.assert_allclose(small, full, rtol=2e-5, atol=1e-6)
+    # a different seed gives a different image
+    other, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, seed=12345))
+    assert not np.array_equal(other, full)
+
+
+def test_depth_one_and_counts(rt, ob, ctx):
+    osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    sc = mirror(rt, ctx, osc)
+    cam = product_camera(rt, osc, 64, 64)
+    p = rt.Scene.params(64, 64, 4, 1, osc.sky, flags=rt.RENDER_COUNT_VISITS | rt.RENDER_PROFILE)
+    img, st = sc.render(cam, p)
+    assert st["rays_traced"] == st["paths"] == 64 * 64 * 4
+    assert st["trace_launches"] == 1 and st["box_tests"] > 0 and st["tri_tests"] > 0
+    assert st["ms_trace"] > 0
+    # depth 1: only emitters and sky are visible; the light is 10 => pixel sums are 0 or 4*10
+    assert img.max() <= 40.0 + 1e-3
+
+
+def test_tonemap_matches_oracle(rt, ob, ctx):
+    rng = np.random.default_rng(0)
+    acc = (rng.uniform(0, 3, (5000, 3)) ** 3).astype(np.float32)
+    acc[0] = [0, np.nan, np.inf]
+    acc[1] = [-1.0, 1e-30, 16.0]
+    want = ob.tonemap(acc, 16)
+    got = ctx.tonemap(acc, 16)
+    assert np.array_equal(got, want)

@@ -1,0 +1,127 @@
+"""Per-ray hit parity of the HIP closest-hit kernel (through rt_trace) against the oracle's
+Hittable::hit restatement: primitive id exact, t bit-exact (the stated bar is 1e-5 relative;
+identical topology, boxes and arithmetic make it exact, so the tests demand exact)."""
+import numpy as np
+import pytest
+
+from helpers import asset, assert_hits_equal, mirror, random_rays, random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_pair(rt, ctx, oscene):
+    return oscene, mirror(rt, ctx, oscene)
+
+
+@pytest.mark.parametrize("name", ["cornell_box_plane.obj", "cornell_box.obj"])
+def test_cornell_camera_and_bounce_rays(rt, ob, ctx, name):
+    osc, sc = _scene_pair(rt, ctx, ob.Scene.cornell_box(asset(name)))
+    rays = osc.record_rays(96, 96, 4, 8, cap=200000, stride=1)
+    assert len(rays) > 50000
+    want, _ = osc.trace(rays)
+    got = sc.trace(rays)
+    assert_hits_equal(got, want)
+    assert (want["prim_id"] != ob.MISS).mean() > 0.5
+
+
+def test_world1_spheres(rt, ob, ctx):
+    osc, sc = _scene_pair(rt, ctx, ob.Scene.world1())
+    rays = osc.record_rays(160, 90, 4, 6, cap=200000)
+    want, _ = osc.trace(rays)
+    assert_hits_equal(sc.trace(rays), want)
+    rr = random_rays(ob, 3, 100000, -6.0, 6.0)
+    want, _ = osc.trace(rr)
+    assert_hits_equal(sc.trace(rr), want)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_world2_mesh_plus_sphere(rt, ob, ctx, variant):
+    osc, sc = _scene_pair(rt, ctx, ob.Scene.world2(asset("thing.obj"), variant))
+    rays = osc.record_rays(96, 96, 4, 6, cap=200000)
+    want, _ = osc.trace(rays)
+    assert_hits_equal(sc.trace(rays), want)
+
+
+@pytest.mark.parametrize("root", [0, 2])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_scenes(rt, ob, ctx, seed, root):
+    mats, objects, _ = random_scene(ob, seed, n_spheres=30 + 7 * seed, n_meshes=seed, tris_per_mesh=50 * seed)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(ctx, mats, objects, root)
+    rays = random_rays(ob, seed + 10, 150000, -12.0, 12.0)
+    for t_min, t_max in [(0.001, np.inf), (0.05, 1.0)]:
+        want, _ = osc.trace(rays, t_min, t_max)
+        assert_hits_equal(sc.trace(rays, t_min, t_max), want)
+
+
+def test_degenerate_scenes(rt, ob, ctx):
+    mats, _, _ = random_scene(ob, 5)
+    rays = random_rays(ob, 1, 5000, -3.0, 3.0)
+    rng = np.random.default_rng(0)
+    from helpers import random_mesh
+    cases = []
+    one_sphere = np.zeros(1, dtype=ob.sphere_dt)
+    one_sphere["r"] = 1.0
+    cases.append(([("spheres", one_sphere)], ob.ROOT_BVH))        # Bvh of one object: left only
+    cases.append(([("spheres", one_sphere)], ob.ROOT_SINGLE))
+    cases.append(([], ob.ROOT_BVH))                               # empty Bvh: zero box, no children
+    cases.append(([("mesh", random_mesh(ob, rng, 0))], ob.ROOT_SINGLE))   # MeshBvhNode::None
+    for n in (1, 2, 3, 5):
+        cases.append(([("mesh", random_mesh(ob, rng, n, extent=2.0))], ob.ROOT_SINGLE))
+    two = np.zeros(2, dtype=ob.sphere_dt)
+    two["r"] = [1.0, 0.5]
+    two["c"][1] = [0.5, 0.2, 0.1]
+    cases.append(([("spheres", two)], ob.ROOT_BVH))               # two objects: left = last
+    for objects, root in cases:
+        osc = ob.Scene.from_description(mats, objects, root)
+        sc = rt.Scene(ctx, mats, objects, root)
+        want, _ = osc.trace(rays)
+        assert_hits_equal(sc.trace(rays), want)
+
+
+def test_ties_between_coincident_primitives(rt, ob, ctx):
+    """Exact-t ties: triangles keep the first found in the reference's visiting order
+    (t < t_max, shape.rs:297); spheres let a later one replace (t_max < root, shape.rs:32)."""
+    mats, _, _ = random_scene(ob, 5)
+    rng = np.random.default_rng(4)
+    from helpers import random_mesh
+    base = random_mesh(ob, rng, 20, extent=2.0)
+    dup = np.concatenate([base, base, base[::-1]])                # every triangle three times
+    dup["mat"] = np.arange(len(dup)) % 6
+    sp = np.zeros(6, dtype=ob.sphere_dt)
+    sp["r"] = 1.0
+    sp["c"][:] = [[0, 0, 0], [0, 0, 0], [3, 0, 0], [3, 0, 0], [3, 0, 0], [0, 3, 0]]
+    sp["mat"] = np.arange(6)
+    rays = random_rays(ob, 2, 100000, -4.0, 4.0)
+    for objects, root in [([("mesh", dup)], ob.ROOT_SINGLE), ([("spheres", sp)], ob.ROOT_BVH),
+                          ([("spheres", sp)], ob.ROOT_LIST), ([("mesh", dup), ("spheres", sp)], ob.ROOT_BVH)]:
+        osc = ob.Scene.from_description(mats, objects, root)
+        sc = rt.Scene(ctx, mats, objects, root)
+        want, _ = osc.trace(rays)
+        assert_hits_equal(sc.trace(rays), want)
+
+
+def test_visit_counters_match_oracle(rt, ob, ctx):
+    import torch
+    osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    sc = mirror(rt, ctx, osc)
+    rays = osc.record_rays(64, 64, 2, 6, cap=50000)
+    want, st = osc.trace(rays, nthreads=4)
+    d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 6)).cuda()
+    d_hits = torch.zeros(len(rays) * 10, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    counts = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
+    assert counts == (st["box_tests"], st["tri_tests"], st["sph_tests"])
+    got = d_hits.cpu().numpy().view(rt.hit_dt)
+    assert_hits_equal(got, want)
+
+
+def test_empty_batch_and_errors(rt, ob, ctx):
+    osc = ob.Scene.world1()
+    sc = mirror(rt, ctx, osc)
+    assert len(sc.trace(np.zeros(0, dtype=rt.ray_dt))) == 0
+    with pytest.raises(rt.RtError):
+        mats = np.zeros(1, dtype=rt.material_dt)
+        sp = np.zeros(1, dtype=rt.sphere_dt)
+        sp["mat"] = 3                                             # out of range
+        rt.Scene(ctx, mats, [("spheres", sp)])
