@@ -10,6 +10,14 @@ import os
 
 import numpy as np
 
+# PyTorch (device memory, streams, torch.distributed) ships its own copy of the HIP runtime
+# under the same soname.  Two HIP/HSA runtimes in one process do not work ("No HIP GPUs are
+# available"), so torch's copy must be the one that is resident before librt_amd.so is loaded.
+try:
+    import torch  # noqa: F401
+except ImportError:  # a torch-free process uses the system runtime the library was linked to
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 ASSET_DIR = os.path.join(_HERE, "assets")
