@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: Mrays/s of the wavefront path tracer on the Cornell box
+(cornell_box_plane.obj, 1024x1024, 1024 spp, max depth 6), whole job over N GPUs.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one full render of the frame: every rank renders its share (interleaved row bands x
+a sample range), then one RCCL sum-reduce combines the accumulation buffers on rank 0.  Scene
+build, BVH upload and OBJ parsing are outside the timed region.  1 ray = 1 closest-hit query.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import raytracer_amd as rt                                     # noqa: E402
+from raytracer_amd import distributed as D                     # noqa: E402
+from raytracer_amd.partition import partition                  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, GB/s
+WORKLOADS = {
+    # name: (constructor, width, height, spp, max depth)
+    "cornell_plane_1024_1k": ("cornell_plane", 1024, 1024, 1024, 6),
+    "world1_1080p_256": ("world1", 1920, 1080, 256, 6),
+    "thing_glass_2048_512": ("world2_glass", 2048, 2048, 512, 6),
+    "cornell_full_512_64": ("cornell", 512, 512, 64, 8),
+}
+
+
+def make_world(ctx, kind):
+    if kind == "cornell_plane":
+        return rt.World.cornell_box(ctx, os.path.join(rt.ASSET_DIR, "cornell_box_plane.obj"))
+    if kind == "cornell":
+        return rt.World.cornell_box(ctx, os.path.join(rt.ASSET_DIR, "cornell_box.obj"))
+    if kind == "world1":
+        return rt.World.world1(ctx)
+    if kind == "world2_glass":
+        return rt.World.world2(ctx, variant=1)
+    raise ValueError(kind)
+
+
+def trace_bytes_per_ray(n_box, n_tri, n_sph):
+    """Algorithmic bytes the closest-hit kernel moves per ray: 32 B per box test (24 B box + 8 B
+    links), 36 B per triangle test (three positions), 16 B per sphere test (centre + radius),
+    plus the ray record read (origin, direction, path slot, rng key: 32 B), the hit record written
+    (8 B) and the queue index written (4 B)."""
+    return 32.0 * n_box + 36.0 * n_tri + 16.0 * n_sph + 32.0 + 8.0 + 4.0
+
+
+def cpu_baseline(kind, width, height, depth, budget_s):
+    """The oracle's tile-per-task renderer on the host cores, on a bounded sample of the workload
+    (same scene and resolution, fewer samples per pixel)."""
+    from oracle import binding as ob
+    path = os.path.join(rt.ASSET_DIR, "cornell_box_plane.obj")
+    if kind == "cornell_plane":
+        osc = ob.Scene.cornell_box(path)
+    elif kind == "cornell":
+        osc = ob.Scene.cornell_box(os.path.join(rt.ASSET_DIR, "cornell_box.obj"))
+    elif kind == "world1":
+        osc = ob.Scene.world1()
+    else:
+        osc = ob.Scene.world2(os.path.join(rt.ASSET_DIR, "thing.obj"), 1)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    # calibrate on 1 spp, then pick the spp that fills the budget
+    _, _, st = osc.render(width, height, 1, depth, nthreads=threads, want_image=False)
+    spp = int(max(1, min(64, budget_s / max(st["seconds"], 1e-3))))
+    _, _, st = osc.render(width, height, spp, depth, nthreads=threads, want_image=False)
+    return {
+        "value": round(st["rays"] / st["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+        "kind": "port",
+        "sample": f"{kind} {width}x{height}, {spp} spp of the workload's samples, depth {depth}, "
+                  f"64x64 tiles, {st['rays']} rays in {st['seconds']:.1f} s",
+        "box_tests_per_ray": round(st["box_tests"] / st["rays"], 2),
+        "tri_tests_per_ray": round(st["tri_tests"] / st["rays"], 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell_plane_1024_1k", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debugging)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--max-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    kind, width, height, spp, depth = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+
+    ctx = rt.Context(local)
+    t0 = time.time()
+    wld = make_world(ctx, kind)
+    build_s = time.time() - t0
+    cam = wld.camera(width, height)
+    rects, samples = partition(width, height, spp, world, rank)
+    accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
+
+    def render(flags, smp, want_stats=True):
+        tot = None
+        for rect in rects:
+            p = wld.params(width, height, spp, depth, rect=rect, samples=smp, flags=flags, max_paths=args.max_paths)
+            st = wld.scene.render_device(cam, p, accum.data_ptr(), want_stats=want_stats)
+            if st is not None:
+                tot = st if tot is None else {k: tot[k] + st[k] for k in st}
+        return tot
+
+    def step(flags):
+        accum.zero_()
+        torch.cuda.current_stream().synchronize()          # the renderer runs on its own stream
+        st = render(flags, samples)                        # returns after the stream has drained
+        D.reduce_to_root(accum)
+        return st
+
+    # per-ray visit counts for the roofline: a counting pass over a few samples (not timed)
+    cs = (samples[0], min(samples[1], samples[0] + 4))
+    accum.zero_()
+    torch.cuda.synchronize()
+    cst = render(rt.RENDER_COUNT_VISITS, cs)
+    n_box = cst["box_tests"] / cst["rays_traced"]
+    n_tri = cst["tri_tests"] / cst["rays_traced"]
+    n_sph = cst["sph_tests"] / cst["rays_traced"]
+
+    for _ in range(args.warmup):
+        step(rt.RENDER_PROFILE)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    rays = 0
+    ms_trace = ms_shade = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        st = step(rt.RENDER_PROFILE)
+        rays += st["rays_traced"]
+        ms_trace += st["ms_trace"]
+        ms_shade += st["ms_shade"]
+        launches += st["trace_launches"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    stats = torch.tensor([elapsed, float(rays), ms_trace, float(launches)], dtype=torch.float64, device=dev)
+    mx = stats.clone()
+    sm = stats.clone()
+    if world > 1:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    elapsed_max = float(mx[0])
+    total_rays = float(sm[1])
+
+    if rank == 0:
+        mean = accum.view(height, width, 3).mean().item() / spp
+        value = total_rays / elapsed_max / 1e6
+        bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph)
+        # rank 0's closest-hit kernel: algorithmic bytes of its launches / their summed duration
+        achieved = bytes_per_ray * rays / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
+        out = {
+            "metric": "Mrays/sec (whole node), Cornell box 1024^2 1k spp",
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
+                       "partition": f"{len(rects)} row-band rect(s) x samples [{samples[0]},{samples[1]}) per rank",
+                       "rays_per_step": int(total_rays / args.steps), "paths_per_step": width * height * spp,
+                       "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3)},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_trace (closest hit)",
+                "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                "bytes_per_ray": round(bytes_per_ray, 1),
+                "tests_per_ray": {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)},
+                "avg_launch_ms": round(ms_trace / max(launches, 1), 4), "launches": launches,
+                "trace_ms_per_step": round(ms_trace / args.steps, 2),
+                "shade_ms_per_step": round(ms_shade / args.steps, 2),
+            },
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(kind, width, height, depth, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

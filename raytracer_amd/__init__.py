@@ -91,6 +91,25 @@ def _load():
         "rt_render_device": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
         "rt_tonemap": (i32, [vp, vp, u32, vp, sz]),
         "rt_tonemap_device": (i32, [vp, vp, u32, vp, sz]),
+        # host scene layer (include/rt_host.h)
+        "rt_world_create_world1": (i32, [vp, pp]),
+        "rt_world_create_world2": (i32, [vp, C.c_char_p, i32, pp]),
+        "rt_world_create_cornell_box": (i32, [vp, C.c_char_p, pp]),
+        "rt_world_create_soup": (i32, [vp, C.c_uint64, u32, u32, pp]),
+        "rt_world_destroy": (None, [vp]),
+        "rt_world_scene": (vp, [vp]),
+        "rt_world_sky_intensity": (f32, [vp]),
+        "rt_world_camera": (i32, [vp, f32, vp]),
+        "rt_world_num_materials": (sz, [vp]),
+        "rt_world_get_materials": (i32, [vp, vp]),
+        "rt_world_num_objects": (sz, [vp]),
+        "rt_world_object_info": (i32, [vp, sz, C.POINTER(sz)]),
+        "rt_world_get_sphere": (i32, [vp, sz, vp]),
+        "rt_world_get_mesh": (i32, [vp, sz, vp]),
+        "rt_world_root_kind": (i32, [vp]),
+        "rt_camera_setup": (i32, [vp, vp, vp, f32, f32, f32, f32, vp]),
+        "rt_world_render": (i32, [vp, u32, u32, u32, u32, C.c_uint64, vp, C.POINTER(Stats)]),
+        "rt_obj_count": (i32, [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -106,6 +125,13 @@ ABI_SYMBOLS = [
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_trace",
     "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
+]
+HOST_SYMBOLS = [
+    "rt_world_create_world1", "rt_world_create_world2", "rt_world_create_cornell_box",
+    "rt_world_create_soup", "rt_world_destroy", "rt_world_scene", "rt_world_sky_intensity",
+    "rt_world_camera", "rt_world_num_materials", "rt_world_get_materials", "rt_world_num_objects",
+    "rt_world_object_info", "rt_world_get_sphere", "rt_world_get_mesh", "rt_world_root_kind",
+    "rt_camera_setup", "rt_world_render", "rt_obj_count",
 ]
 
 
@@ -158,8 +184,18 @@ class Context:
 class Scene:
     """rt_scene.  ctx=None gives a host-only scene (flattening can be inspected, nothing runs)."""
 
+    @classmethod
+    def _borrow(cls, ctx, handle):
+        """A view of a scene owned by a World."""
+        s = cls.__new__(cls)
+        s.ctx = ctx
+        s.h = C.c_void_p(handle)
+        s._borrowed = True
+        return s
+
     def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH):
         self.ctx = ctx
+        self._borrowed = False
         h = C.c_void_p()
         _check(lib.rt_scene_create(ctx.h if ctx is not None else None, C.byref(h)))
         self.h = h
@@ -179,7 +215,8 @@ class Scene:
 
     def close(self):
         if getattr(self, "h", None):
-            lib.rt_scene_destroy(self.h)
+            if not self._borrowed:
+                lib.rt_scene_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -236,3 +273,114 @@ class Scene:
         _check(lib.rt_render_device(self.h, _ptr(cam), C.byref(params), d_accum,
                                     C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+
+class World:
+    """rt_world: the reference's World {camera, hittable, sky_intensity} (main.rs:69-73) built by
+    the C++ host layer and committed to the GPU.  ctx=None builds a host-only world."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+        self.scene = Scene._borrow(ctx, lib.rt_world_scene(handle))
+
+    @staticmethod
+    def _make(ctx, fn, *args):
+        h = C.c_void_p()
+        _check(fn(ctx.h if ctx is not None else None, *args, C.byref(h)))
+        return World(ctx, h)
+
+    @staticmethod
+    def world1(ctx):
+        return World._make(ctx, lib.rt_world_create_world1)
+
+    @staticmethod
+    def world2(ctx, thing_obj=None, variant=0):
+        path = thing_obj or os.path.join(ASSET_DIR, "thing.obj")
+        return World._make(ctx, lib.rt_world_create_world2, path.encode(), variant)
+
+    @staticmethod
+    def cornell_box(ctx, obj_path=None):
+        path = obj_path or os.path.join(ASSET_DIR, "cornell_box.obj")
+        return World._make(ctx, lib.rt_world_create_cornell_box, path.encode())
+
+    @staticmethod
+    def soup(ctx, n_tris, grid=64, seed=12345):
+        return World._make(ctx, lib.rt_world_create_soup, n_tris, grid, seed)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.scene.close()
+            lib.rt_world_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def sky(self):
+        return lib.rt_world_sky_intensity(self.h)
+
+    @property
+    def root_kind(self):
+        return lib.rt_world_root_kind(self.h)
+
+    def camera(self, width, height):
+        """Camera::setup(width / height) -> rt_camera record."""
+        out = np.zeros(1, dtype=camera_dt)
+        _check(lib.rt_world_camera(self.h, np.float32(width) / np.float32(height), _ptr(out)))
+        return out[0]
+
+    def materials(self):
+        out = np.zeros(lib.rt_world_num_materials(self.h), dtype=material_dt)
+        _check(lib.rt_world_get_materials(self.h, _ptr(out)))
+        return out
+
+    def objects(self):
+        """[('spheres', sphere_dt[]) | ('mesh', triangle_dt[])] in insertion order."""
+        out, run = [], []
+        for i in range(lib.rt_world_num_objects(self.h)):
+            cnt = C.c_size_t(0)
+            kind = lib.rt_world_object_info(self.h, i, C.byref(cnt))
+            if kind == 0:
+                sp = np.zeros(1, dtype=sphere_dt)
+                _check(lib.rt_world_get_sphere(self.h, i, _ptr(sp)))
+                run.append(sp)
+            else:
+                if run:
+                    out.append(("spheres", np.concatenate(run)))
+                    run = []
+                tr = np.zeros(cnt.value, dtype=triangle_dt)
+                _check(lib.rt_world_get_mesh(self.h, i, _ptr(tr)))
+                out.append(("mesh", tr))
+        if run:
+            out.append(("spheres", np.concatenate(run)))
+        return out
+
+    def params(self, width, height, spp, max_bounces, **kw):
+        return Scene.params(width, height, spp, max_bounces, self.sky, **kw)
+
+    def render(self, width, height, spp, max_bounces, seed=DEFAULT_SEED):
+        """render() drop-in: full frame, samples [0, spp); returns (sums[H,W,3], stats)."""
+        acc = np.zeros((height, width, 3), dtype=np.float32)
+        st = Stats()
+        _check(lib.rt_world_render(self.h, width, height, spp, max_bounces, seed, _ptr(acc), C.byref(st)))
+        return acc, st.as_dict()
+
+
+def camera_setup(look_from, look_at, vup, vfov, aperture, focus_dist, aspect_ratio):
+    f = np.ascontiguousarray(look_from, dtype=np.float32)
+    a = np.ascontiguousarray(look_at, dtype=np.float32)
+    u = np.ascontiguousarray(vup, dtype=np.float32)
+    out = np.zeros(1, dtype=camera_dt)
+    _check(lib.rt_camera_setup(_ptr(f), _ptr(a), _ptr(u), vfov, aperture, focus_dist, aspect_ratio, _ptr(out)))
+    return out[0]
+
+
+def obj_count(path):
+    t, m, f = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+    _check(lib.rt_obj_count(path.encode(), C.byref(t), C.byref(m), C.byref(f)))
+    return t.value, m.value, f.value

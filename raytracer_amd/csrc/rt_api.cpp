@@ -23,6 +23,10 @@ int fail(int code, const std::string& msg) {
     g_last_error = msg;
     return code;
 }
+}  // namespace
+// lets the host scene layer (host/rt_host.cpp) report through rt_last_error()
+void rt_internal_set_error(const char* msg) { g_last_error = msg ? msg : ""; }
+namespace {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \

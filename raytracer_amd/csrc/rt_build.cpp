@@ -36,7 +36,6 @@ inline Box surrounding(const Box& a, const Box& b) { // math.rs:167-172 (self = 
     for (int k = 0; k < 3; k++) { r.lo[k] = minps(a.lo[k], b.lo[k]); r.hi[k] = maxps(a.hi[k], b.hi[k]); }
     return r;
 }
-inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 struct Builder {

@@ -1,0 +1,45 @@
+"""One process per GPU: render this rank's share, then one sum-reduce of the accumulation
+buffers to rank 0 (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU).
+The reduce is the only collective of the path."""
+import os
+
+import torch
+import torch.distributed as dist
+
+from .partition import partition
+
+
+def init_from_env(backend=None):
+    """(rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def reduce_to_root(accum):
+    """Sum the per-rank accumulation buffers into rank 0's (in place).  No-op for one rank."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    return accum
+
+
+def render_partitioned(render_rect, width, height, spp, rank, world_size, accum):
+    """Runs `render_rect(rect, (s0, s1), accum)` for every rectangle of this rank's partition, then
+    reduces.  `render_rect` adds the linear sample sums of that rectangle/sample range into
+    `accum` (the GPU path passes a closure over Scene.render_device).  Returns accum (complete
+    on rank 0 only)."""
+    rects, samples = partition(width, height, spp, world_size, rank)
+    for rect in rects:
+        render_rect(rect, samples, accum)
+    return reduce_to_root(accum)

@@ -1,0 +1,260 @@
+"""CPU-side checks of the product's host code (no GPU needed): the C-ABI library loads and
+exports every declared symbol, the C++ scene layer reproduces the oracle's scene descriptions,
+and the flattened pre-order entry array encodes the reference's traversal (checked by walking it
+in Python with f32 arithmetic and comparing hits with the oracle)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, asset, random_rays, random_scene
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(rt):
+    names = _declared("rt_abi.h") + _declared("rt_host.h")
+    assert len(names) >= 35
+    raw = ctypes.CDLL(rt.LIB_PATH)
+    missing = [n for n in names if not hasattr(raw, n)]
+    assert not missing, missing
+    assert sorted(rt.ABI_SYMBOLS) == _declared("rt_abi.h")
+    assert sorted(rt.HOST_SYMBOLS) == _declared("rt_host.h")
+
+
+def test_struct_layouts_match_header(rt):
+    assert rt.material_dt.itemsize == 24 and rt.sphere_dt.itemsize == 20
+    assert rt.triangle_dt.itemsize == 52 and rt.ray_dt.itemsize == 24
+    assert rt.hit_dt.itemsize == 40 and rt.camera_dt.itemsize == 76
+    assert ctypes.sizeof(rt.RenderParams) == 64 and ctypes.sizeof(rt.Stats) == 72
+
+
+def test_no_gpu_fails_loudly(rt):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError):
+        rt.Context(0)
+    w = rt.World.cornell_box(None, asset("cornell_box_plane.obj"))      # host-only world
+    with pytest.raises(rt.RtError, match="host-only"):
+        w.scene.trace(np.zeros(4, dtype=rt.ray_dt))
+    with pytest.raises(rt.RtError, match="host-only"):
+        w.render(16, 16, 1, 2)
+
+
+def test_argument_errors(rt):
+    mats = np.zeros(1, dtype=rt.material_dt)
+    sp = np.zeros(1, dtype=rt.sphere_dt)
+    sp["mat"] = 1
+    with pytest.raises(rt.RtError, match="material index"):
+        rt.Scene(None, mats, [("spheres", sp)])
+    with pytest.raises(rt.RtError, match="exactly one object"):
+        rt.Scene(None, mats, [], rt.ROOT_SINGLE)
+    with pytest.raises(rt.RtError, match="no materials"):
+        rt.Scene(None, mats[:0], [])
+    bad = mats.copy()
+    bad["kind"] = 9
+    with pytest.raises(rt.RtError, match="material kind"):
+        rt.Scene(None, bad, [])
+    with pytest.raises(rt.RtError):
+        rt.World.cornell_box(None, "/nonexistent/file.obj")
+    with pytest.raises(rt.RtError):
+        rt.obj_count("/nonexistent/file.obj")
+
+
+def _resolved(materials, objects):
+    """Object list with material indices replaced by the material records they point at."""
+    out = []
+    for kind, arr in objects:
+        geo = b"".join(np.ascontiguousarray(arr[n]).tobytes() for n in arr.dtype.names if n != "mat")
+        out.append((kind, geo, materials[arr["mat"]].tobytes()))
+    return out
+
+
+@pytest.mark.parametrize("which", ["world1", "world2", "world2_glass", "cornell", "cornell_plane"])
+def test_scene_constructors_match_oracle(rt, ob, which):
+    if which == "world1":
+        w, o = rt.World.world1(None), ob.Scene.world1()
+    elif which == "world2":
+        w, o = rt.World.world2(None, asset("thing.obj"), 0), ob.Scene.world2(asset("thing.obj"), 0)
+    elif which == "world2_glass":
+        w, o = rt.World.world2(None, asset("thing.obj"), 1), ob.Scene.world2(asset("thing.obj"), 1)
+    elif which == "cornell":
+        w, o = rt.World.cornell_box(None, asset("cornell_box.obj")), ob.Scene.cornell_box(asset("cornell_box.obj"))
+    else:
+        w = rt.World.cornell_box(None, asset("cornell_box_plane.obj"))
+        o = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    assert _resolved(w.materials(), w.objects()) == _resolved(o.materials(), o.objects())
+    assert w.root_kind == o.root_kind and w.sky == o.sky
+    for wd, ht in [(1920, 1080), (512, 512), (100, 77)]:
+        assert w.camera(wd, ht).tobytes() == o.camera(np.float32(wd) / np.float32(ht)).tobytes()
+    assert w.scene.num_prims == o.num_prims
+
+
+def test_obj_loader_counts(rt, ob):
+    for name in ["cornell_box.obj", "cornell_box_plane.obj", "thing.obj"]:
+        assert rt.obj_count(asset(name)) == ob.obj_count(asset(name))
+
+
+def test_obj_loader_syntax_variants(rt, ob, tmp_path):
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 1 1 1\nnewmtl  b \n")
+    text = """# comment
+mtllib m.mtl
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 0.5 1
+vt 0 0
+vn 0 0 1
+vn 0 1 0
+g first
+usemtl a
+f 1/1/1 2/1/1 3/1/1 4/1/1
+f -5//1 -4//1 -1//2
+usemtl b
+f 1//2 2//2 5//2
+f 1//1 2//1 3//1 4//1 5//1
+l 1 2
+p 1
+o second
+usemtl nosuch
+f 3//1 4//1 5//1
+"""
+    (tmp_path / "t.obj").write_text(text.replace("\n", "\r\n"))
+    path = str(tmp_path / "t.obj")
+    want = ob.obj_count(path)
+    assert rt.obj_count(path) == want == (8, 3, 5)      # quad 2 + tri 1 | tri 1 + pentagon 3 | tri 1
+
+
+def test_camera_setup_matches_oracle(rt, ob):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        f, a = rng.uniform(-10, 10, 3), rng.uniform(-10, 10, 3)
+        vfov, ap, focus, aspect = rng.uniform(10, 120), rng.uniform(0, 0.5), rng.uniform(0.5, 300), rng.uniform(0.5, 2)
+        s = ob.Scene.from_description(np.zeros(1, dtype=ob.material_dt), [], ob.ROOT_BVH,
+                                      camera=(f, a, [0, 0, 1], vfov, ap, focus))
+        got = rt.camera_setup(f, a, [0, 0, 1], vfov, ap, focus, aspect)
+        assert got.tobytes() == s.camera(aspect).tobytes()
+
+
+# ---- the flattened entry array --------------------------------------------------------------
+F = np.float32
+
+
+def _dot(a, b):
+    return F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2])
+
+
+def _walk(entries, o, d, t_min, t_max):
+    """Pre-order walk with skip links, f32 arithmetic; mirrors the device loop."""
+    ent_u = entries.view(np.uint32)
+    n = len(entries)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = [F(1.0) / d[k] for k in range(3)]
+        best_t, best = F(t_max), 0xFFFFFFFF
+        i = 0
+        eps = F(1.1920929e-7)
+        while i < n:
+            e = entries[i]
+            w = int(ent_u[i, 3])
+            tag = w >> 30
+            if tag == 0:
+                tmn, tmx = F(t_min), best_t
+                miss = False
+                for k in range(3):
+                    t0 = F(F(e[k] - o[k]) * inv[k])
+                    t1 = F(F(e[4 + k] - o[k]) * inv[k])
+                    if inv[k] < 0:
+                        t0, t1 = t1, t0
+                    tmn = t0 if t0 > tmn else tmn
+                    tmx = t1 if t1 < tmx else tmx
+                    if tmx <= tmn:
+                        miss = True
+                        break
+                i = (w & 0x3FFFFFFF) if miss else i + 1
+            elif tag == 1:
+                v0, e1, e2 = e[0:3], e[4:7], e[8:11]
+                p = [F(F(d[1] * e2[2]) - F(d[2] * e2[1])), F(F(d[2] * e2[0]) - F(d[0] * e2[2])),
+                     F(F(d[0] * e2[1]) - F(d[1] * e2[0]))]
+                det = _dot(e1, p)
+                if not (abs(det) < eps):
+                    invd = F(1.0) / det
+                    tv = [F(o[k] - v0[k]) for k in range(3)]
+                    u = F(_dot(tv, p) * invd)
+                    if not (u < 0 or u > 1):
+                        q = [F(F(tv[1] * e1[2]) - F(tv[2] * e1[1])), F(F(tv[2] * e1[0]) - F(tv[0] * e1[2])),
+                             F(F(tv[0] * e1[1]) - F(tv[1] * e1[0]))]
+                        v = F(_dot(d, q) * invd)
+                        if not (v < 0 or F(u + v) > 1):
+                            t = F(_dot(e2, q) * invd)
+                            if t >= t_min and t < best_t:
+                                best_t, best = t, int(ent_u[i, 7])
+                i += 1
+            else:
+                c, r = e[0:3], e[4]
+                oc = [F(o[k] - c[k]) for k in range(3)]
+                a = _dot(d, d)
+                hb = _dot(oc, d)
+                cc = F(_dot(oc, oc) - F(r * r))
+                disc = F(F(hb * hb) - F(a * cc))
+                if not (disc < 0):
+                    sq = np.sqrt(disc)
+                    root = F(F(-hb - sq) / a)
+                    ok = True
+                    if root < t_min or best_t < root:
+                        root = F(F(-hb + sq) / a)
+                        if root < t_min or best_t < root:
+                            ok = False
+                    if ok:
+                        best_t, best = root, int(ent_u[i, 7])
+                i += 1
+    return best, best_t
+
+
+@pytest.mark.parametrize("root", [0, 2])
+def test_flattened_entries_encode_reference_traversal(rt, ob, root):
+    mats, objects, _ = random_scene(ob, 11 + root, n_spheres=9, n_meshes=2, tris_per_mesh=13, extent=4.0)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root)
+    ent = sc.entries()
+    assert len(ent) == sc.num_entries and sc.num_prims == osc.num_prims
+    rays = random_rays(ob, 5, 400, -5.0, 5.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    for k in range(len(rays)):
+        prim, t = _walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))
+        assert prim == want["prim_id"][k]
+        if prim != 0xFFFFFFFF:
+            assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+
+
+def test_entry_layout_small_cases(rt, ob):
+    mats = np.zeros(2, dtype=rt.material_dt)
+    mats["kind"] = [rt.MAT_LAMBERT, rt.MAT_METAL]
+    tr = np.zeros(3, dtype=rt.triangle_dt)
+    tr["p"][:, 1, 0] = 1.0
+    tr["p"][:, 2, 1] = 1.0
+    tr["p"][:, :, 2] = [[0.0], [1.0], [2.0]]
+    tr["n0"][:, 2] = 1.0
+    tr["mat"] = [0, 1, 0]
+    ent = rt.Scene(None, mats, [("mesh", tr)], rt.ROOT_SINGLE).entries()
+    u = ent.view(np.uint32)
+    # 3 triangles sorted on x (all equal => stable): left = build([t0]) = leaf; right = build([t1,t2])
+    # = box{ t2 (pop = last), t1 }.  Pre-order: box, t0, box, t2, t1.
+    assert len(ent) == 5
+    assert [int(x >> 30) for x in u[:, 3]] == [0, 1, 0, 1, 1]
+    assert [int(x) for x in u[[1, 3, 4], 7]] == [0, 2, 1]
+    assert int(u[0, 3] & 0x3FFFFFFF) == 5 and int(u[2, 3] & 0x3FFFFFFF) == 5
+    np.testing.assert_array_equal(ent[0, 0:3], np.float32([0, 0, 0]) - np.float32(0.0001))
+    np.testing.assert_array_equal(ent[0, 4:7], np.float32([1, 1, 2]) + np.float32(0.0001))
+    np.testing.assert_array_equal(ent[2, 0:3], np.float32([0, 0, 1]) - np.float32(0.0001))
+    assert int(u[3, 11]) == 0 and int(u[4, 11]) == (1 | (1 << 28))     # material | kind << 28
+    np.testing.assert_array_equal(ent[1, 4:7], [1, 0, 0])              # v0v1
+    np.testing.assert_array_equal(ent[1, 8:11], [0, 1, 0])             # v0v2

@@ -1,0 +1,239 @@
+"""Pins the CPU oracle against the known answers available for this path.
+
+The reference has no tests or golden vectors of its own.  tests/golden/reference_kat.json holds
+values derived from the reference's definitions (xorshift32 stream, random01 bit patterns, the
+create_world1 sphere table, OBJ triangle counts); the analytic cases below are hand-derived
+from the formulas in src/shape.rs and src/math.rs.  Anything that depends on glam / tobj
+internals stays "parity unpinned" (see oracle/oracle.h)."""
+import json
+import os
+
+import numpy as np
+
+from helpers import asset
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat.json")))
+
+
+def _bits(f):
+    return int(np.float32(f).view(np.uint32))
+
+
+def test_xorshift32_stream(ob):
+    for seed, want in KAT["xorshift32"].items():
+        assert ob.xorshift32(int(seed), len(want)).tolist() == want
+
+
+def test_random01_bits(ob):
+    got = ob.random01(1, 4).view(np.uint32).tolist()
+    assert got == [int(x, 16) for x in KAT["random01_seed1_bits"]]
+    # (x as f64 / u32::MAX as f64) as f32 rounds up to exactly 1.0 near the top of the range
+    assert ob.random01_of(KAT["random01_one_from"]) == np.float32(1.0)
+    assert ob.random01_of(0xFFFFFFFF) == np.float32(1.0)
+    b = KAT["random01_below_one"]
+    assert _bits(ob.random01_of(b["x"])) == int(b["bits"], 16)
+    assert ob.random01_of(0) == 0.0
+
+
+def test_world1_sphere_table(ob):
+    s = ob.Scene.world1()
+    k = KAT["world1"]
+    objs = s.objects()
+    assert len(objs) == 1 and objs[0][0] == "spheres"
+    sp = objs[0][1]
+    assert len(sp) == k["n_objects"] == s.num_prims
+    pick_to_mat = {0: 0, 1: 2, 2: 3, 3: 4}      # [center, left, right, glass] in the oracle's table
+    for idx, want in k["random_spheres"].items():
+        rec = sp[6 + int(idx)]
+        assert rec["c"].view(np.uint32).tolist() == [int(x, 16) for x in want["center_bits"]]
+        assert rec["mat"] == pick_to_mat[want["material_pick"]]
+        assert rec["r"] == np.float32(0.25)
+    hist = [int((sp["mat"][6:506] == pick_to_mat[i]).sum()) for i in range(4)]
+    assert hist == k["material_pick_histogram"]
+    assert ob.rng_state_after_world1() == k["rng_state_after"]
+    # the fixed spheres and the emitter (main.rs:100-131, 154-158)
+    assert sp["c"][0].tolist() == [0.0, -1.0, -200.5] and sp["r"][0] == 200.0
+    assert sp["c"][4].tolist() == [np.float32(-0.4), np.float32(-1.3), np.float32(-0.5) + np.float32(0.1)]
+    assert sp["c"][506].tolist() == [0.0, 0.0, 50.0] and sp["r"][506] == 12.0
+    mats = s.materials()
+    assert mats["kind"][sp["mat"][506]] == ob.EMISSIVE
+    assert s.sky == np.float32(0.02) and s.root_kind == ob.ROOT_BVH
+
+
+def test_obj_ingest_counts(ob):
+    for name, want in KAT["obj"].items():
+        tris, models, faces = ob.obj_count(asset(name))
+        assert (tris, models, faces) == (want["triangles"], want["models"], want["faces"])
+
+
+def test_cornell_scene(ob):
+    s = ob.Scene.cornell_box(asset("cornell_box.obj"))
+    tr = s.objects()[0][1]
+    assert len(tr) == 23626 and s.root_kind == ob.ROOT_SINGLE
+    room = ob.Scene.cornell_box(asset("cornell_box_plane.obj")).objects()[0][1]["p"].reshape(-1, 3)
+    np.testing.assert_allclose(room.min(0), KAT["cornell_bounds"]["min"], atol=1e-3)
+    np.testing.assert_allclose(room.max(0), KAT["cornell_bounds"]["max"], atol=1e-3)
+    mats = s.materials()
+    # models in file order: floor(white) light ceiling back green red tall_block Sphere(glass) Sphere.001(metal)
+    kinds = mats["kind"][tr["mat"]]
+    assert kinds[6] == ob.EMISSIVE and kinds[7] == ob.EMISSIVE           # the light quad
+    assert (kinds == ob.DIELECTRIC).sum() == 5800 * 2 + 200
+    assert (kinds == ob.METAL).sum() == 5800 * 2 + 200
+    np.testing.assert_allclose(mats["param"][tr["mat"]][kinds == ob.DIELECTRIC], 2.3)
+    # world2: neither MTL name is in the shipped map => everything gets index 0 ("default")
+    w2 = ob.Scene.world2(asset("thing.obj"), 0)
+    assert (w2.objects()[0][1]["mat"] == 0).all() and len(w2.objects()[0][1]) == 450
+
+
+def test_sphere_hit_analytic(ob):
+    mats = np.zeros(1, dtype=ob.material_dt)
+    sp = np.zeros(1, dtype=ob.sphere_dt)
+    sp["r"] = 1.0
+    s = ob.Scene.from_description(mats, [("spheres", sp)], ob.ROOT_SINGLE)
+    rays = np.zeros(4, dtype=ob.ray_dt)
+    rays["o"] = [[-3, 0, 0], [0, 0, 0], [0, 0, 5], [0, 3, 0]]
+    rays["d"] = [[1, 0, 0], [0, 2, 0], [0, 0, 1], [1, 0, 0]]
+    h, st = s.trace(rays, 0.001, np.inf, nthreads=1)
+    assert h["t"][0] == 2.0 and h["front_face"][0] == 1 and h["n"][0].tolist() == [-1.0, 0.0, 0.0]
+    # origin inside: the near root is negative, the far root is taken (shape.rs:31-36); dir length 2
+    assert h["t"][1] == 0.5 and h["front_face"][1] == 0 and h["n"][1].tolist() == [0.0, -1.0, 0.0]
+    assert h["prim_id"][2] == ob.MISS and h["prim_id"][3] == ob.MISS
+    assert st["sph_tests"] == 4 and st["rays"] == 4 and st["hits"] == 2
+    # closed interval: t_max equal to the root still hits (t_max < root is false)
+    h, _ = s.trace(rays[:1], 0.001, 2.0, nthreads=1)
+    assert h["prim_id"][0] == 0
+    h, _ = s.trace(rays[:1], 0.001, np.float32(1.9999999), nthreads=1)
+    assert h["prim_id"][0] == ob.MISS
+
+
+def test_aabb_slab_analytic(ob):
+    lo, hi = [0, 0, 0], [1, 1, 1]
+    assert ob.aabb_hit(lo, hi, [-1, 0.5, 0.5], [1, 0.001, 0.001], 0.001, np.inf)
+    assert ob.aabb_hit(lo, hi, [2, 0.5, 0.5], [-1, 0.001, 0.001], 0.001, np.inf)      # negative direction swaps
+    assert not ob.aabb_hit(lo, hi, [-1, 0.5, 0.5], [-1, 0.001, 0.001], 0.001, np.inf)
+    assert not ob.aabb_hit(lo, hi, [-1, 0.5, 0.5], [1, 0.001, 0.001], 0.001, 0.5)     # t_max cuts it off
+    # zero direction component: inv_d = inf; inside the slab passes, outside fails
+    assert ob.aabb_hit(lo, hi, [-1, 0.5, 0.5], [1, 0, 0], 0.001, np.inf)
+    assert not ob.aabb_hit(lo, hi, [-1, 1.5, 0.5], [1, 0, 0], 0.001, np.inf)
+    # zero-thickness box: t_max <= t_min rejects (the reason compute_aabb pads, shape.rs:225)
+    assert not ob.aabb_hit([0, 0, 0], [1, 1, 0], [0.5, 0.5, -1], [0.001, 0.001, 1], 0.001, np.inf)
+
+
+def test_moller_trumbore_analytic(ob):
+    v0, v1, v2 = [0, 0, 0], [1, 0, 0], [0, 1, 0]
+    hit, back, t, u, v = ob.ray_triangle([0.25, 0.25, 1], [0, 0, -1], v0, v1, v2)
+    assert hit and (t, u, v) == (1.0, 0.25, 0.25)
+    assert not back                               # pvec = d x e2 = (1,0,0), det = e1 . pvec = +1
+    hit, back, t, u, v = ob.ray_triangle([0.25, 0.25, -1], [0, 0, 2], v0, v1, v2)
+    assert hit and back and t == 0.5              # det = -2 < eps; unnormalised direction: t in ray-parameter units
+    assert not ob.ray_triangle([0.75, 0.75, 1], [0, 0, -1], v0, v1, v2)[0]            # u + v > 1
+    assert ob.ray_triangle([0.5, 0.5, 1], [0, 0, -1], v0, v1, v2)[0]                  # on the hypotenuse
+    assert not ob.ray_triangle([-0.1, 0.2, 1], [0, 0, -1], v0, v1, v2)[0]             # u < 0
+    assert not ob.ray_triangle([0.2, 0.2, 1], [1, 0, 0], v0, v1, v2)[0]               # parallel: |det| < eps
+    # behind the origin: the intersection routine itself reports t < 0; the caller's t >= t_min rejects
+    hit, _, t, _, _ = ob.ray_triangle([0.25, 0.25, 1], [0, 0, 1], v0, v1, v2)
+    assert hit and t == -1.0
+
+
+def test_mesh_hit_tie_and_front_face_quirk(ob):
+    mats = np.zeros(2, dtype=ob.material_dt)
+    tr = np.zeros(2, dtype=ob.triangle_dt)
+    tr["p"][:] = [[0, 0, 0], [1, 0, 0], [0, 1, 0]]
+    tr["n0"][:] = [0, 0, 1]
+    tr["mat"] = [0, 1]
+    s = ob.Scene.from_description(mats, [("mesh", tr)], ob.ROOT_SINGLE)
+    rays = np.zeros(2, dtype=ob.ray_dt)
+    rays["o"] = [[0.25, 0.25, 1], [0.25, 0.25, -1]]
+    rays["d"] = [[1e-4, 1e-4, -1], [1e-4, 1e-4, 1]]
+    h, st = s.trace(rays, nthreads=1)
+    # two coincident triangles: build puts the LAST one left (pop()), it is found first and the
+    # second cannot replace it because t < t_max is strict (shape.rs:297)
+    assert h["prim_id"].tolist() == [1, 1] and h["mat"].tolist() == [1, 1]
+    assert st["tri_tests"] == 4 and st["box_tests"] == 2
+    # v1.n agrees with the winding: front_face is true from both sides (shape.rs:299-307)
+    assert h["front_face"].tolist() == [1, 1]
+    assert h["n"][0].tolist() == [0.0, 0.0, 1.0] and h["n"][1].tolist() == [0.0, 0.0, -1.0]
+
+
+def test_bvh_order_and_single_child(ob):
+    mats = np.zeros(1, dtype=ob.material_dt)
+    sp = np.zeros(3, dtype=ob.sphere_dt)
+    sp["r"] = 1.0
+    sp["c"][:, 0] = [6.0, 3.0, 0.0]
+    s = ob.Scene.from_description(mats, [("spheres", sp)], ob.ROOT_BVH)
+    ray = np.zeros(1, dtype=ob.ray_dt)
+    ray["o"] = [-5, 1e-3, 1e-3]
+    ray["d"] = [1, 1e-5, 1e-5]
+    h, st = s.trace(ray, nthreads=1)
+    assert h["prim_id"][0] == 2 and abs(h["t"][0] - 4.0) < 1e-3
+    # sorted on x: [2] | [1, 0]; root box, left Bvh(1 object) box + sphere, right Bvh(2) box culled
+    # by t_max = 4 (its box starts at x = 2, t = 7)
+    assert st["box_tests"] == 3 and st["sph_tests"] == 1
+
+
+def test_tonemap_and_pack(ob):
+    assert ob.rgb_to_u32(1.0, 0.5, 0.0) == (255 << 16) | (127 << 8)
+    assert ob.rgb_to_u32(2.0, -1.0, float("nan")) == (511 & 0xFFFFFFFF) << 16   # no upper clamp in rgb_to_u32 itself
+    acc = np.array([[4.0, 1.0, 0.25], [1e9, 0.0, 4.0]], dtype=np.float32)
+    out = ob.tonemap(acc, 4)
+    assert out[0] == (255 << 16) | (127 << 8) | 63                            # sqrt(1)=1, sqrt(.25)=.5, sqrt(.0625)=.25
+    assert out[1] == (255 << 16) | 255                                        # min(sqrt, 1)
+
+
+def test_scatter_restatement(ob):
+    n = [0.0, 0.0, 1.0]
+    lam = np.zeros(1, dtype=ob.material_dt)
+    lam["rgb"] = [0.1, 0.2, 0.3]
+    ok, att, o, d, state = ob.scatter(lam, [0, 0, 1], [0, 0, -1], [0, 0, 0], n, True, 12345)
+    assert ok and att.tolist() == [np.float32(0.1), np.float32(0.2), np.float32(0.3)]
+    assert abs(np.linalg.norm(d) - 1) < 1e-6 and d[2] > -1e-6 and state != 12345
+    lam["flags"] = 1
+    ok, att, _, _, _ = ob.scatter(lam, [0, 0, 1], [0, 0, -1], [0, 0, 0], n, True, 1)
+    assert att.tolist() == [0.5, 0.5, 1.0]
+    met = np.zeros(1, dtype=ob.material_dt)
+    met["kind"] = ob.METAL
+    met["rgb"] = 0.8
+    ok, att, o, d, state = ob.scatter(met, [0, 0, 1], [2, 0, -2], [0, 0, 0], n, True, 7)
+    assert ok and d.tolist() == [2.0, 0.0, 2.0] and state == 7 * 0 + _state_after(ob, 7, 3)   # fuzz 0: pure mirror, still draws
+    em = np.zeros(1, dtype=ob.material_dt)
+    em["kind"] = ob.EMISSIVE
+    assert not ob.scatter(em, [0, 0, 1], [0, 0, -1], [0, 0, 0], n, True, 1)[0]
+    gl = np.zeros(1, dtype=ob.material_dt)
+    gl["kind"] = ob.DIELECTRIC
+    gl["rgb"] = 1.0
+    gl["param"] = 1.5
+    # normal incidence: cos = 1, sin = 0, reflectance = r0 = 0.04; direction stays (0,0,-1) when refracted
+    for seed in range(1, 40):
+        ok, att, o, d, st = ob.scatter(gl, [0, 0, 1], [0, 0, -3], [0, 0, 0], n, True, seed)
+        assert ok and att.tolist() == [1.0, 1.0, 1.0]
+        assert d.tolist() in ([0.0, 0.0, -1.0], [0.0, 0.0, 1.0])
+    # total internal reflection from inside at a grazing angle draws no random number
+    ok, _, _, d, st = ob.scatter(gl, [0, 0, 0], [1, 0, -0.1], [0, 0, 0], n, False, 99)
+    assert st == 99 and d[2] > 0
+
+
+def _state_after(ob, seed, min_draws):
+    """RNG state after random_in_unit_sphere() from `seed` (rejection loop, 3 draws per try)."""
+    xs = ob.xorshift32(seed, 300)
+    f = np.array([ob.random01_of(int(x)) for x in xs], dtype=np.float32)
+    i = 0
+    while True:
+        p = f[i:i + 3] * np.float32(2.0) + np.float32(-1.0)
+        i += 3
+        if (np.float32(p[0] * p[0]) + np.float32(p[1] * p[1])) + np.float32(p[2] * p[2]) < 1.0:
+            return int(xs[i - 1])
+
+
+def test_render_is_deterministic_and_counts(ob):
+    s = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    a, img, st = s.render(70, 50, 12, 6, nthreads=4)
+    b, img2, st2 = s.render(70, 50, 12, 6, nthreads=1)
+    assert np.array_equal(a, b) and np.array_equal(img, img2) and st["rays"] == st2["rays"]
+    assert st["paths"] == 70 * 50 * 12 and st["paths"] <= st["rays"] <= 6 * st["paths"]
+    assert np.array_equal(ob.tonemap(a, 12).reshape(50, 70), img)
+    c, _, _ = s.render(70, 50, 12, 6, seed_offset=5)
+    assert not np.array_equal(a, c)
+    # depth 1 shows only the emitter (10 per sample) and the sky (< 0.5 per sample)
+    d1, _, st1 = s.render(64, 64, 2, 1)
+    assert st1["rays"] == st1["paths"] and d1.max() == 20.0
+    assert ((d1 <= 1.0) | (d1 >= 10.0)).all()
