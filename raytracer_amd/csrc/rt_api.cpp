@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -59,11 +60,12 @@ struct rt_context {
     hipStream_t stream = nullptr;
     uint32_t grid_cap = 2048;
     // wavefront state, grown on demand and kept between calls
-    DeviceBuffer rayA[2], rayB[2], rayC[2], hits, queue[3], lbuf, ctl, totals, scratch_in, scratch_out;
+    DeviceBuffer rayA[2], rayB[2], rayC[2], hits, queue[3], lbuf, segcnt, qcnt, totals, scratch_in, scratch_out;
+    uint32_t wave_target = 8192;
     size_t capacity = 0;
     std::vector<hipEvent_t> events;
 
-    LaunchCfg cfg() const { return LaunchCfg{(void*)stream, grid_cap}; }
+    LaunchCfg cfg() const { return LaunchCfg{(void*)stream, grid_cap, wave_target}; }
     ~rt_context() {
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
@@ -98,7 +100,6 @@ int ensure_capacity(rt_context* ctx, size_t paths) {
     HIP_TRY(ctx->hits.ensure(paths * 8));
     for (int k = 0; k < 3; k++) HIP_TRY(ctx->queue[k].ensure(paths * 4));
     HIP_TRY(ctx->lbuf.ensure(paths * 16));
-    HIP_TRY(ctx->ctl.ensure(sizeof(BatchCtl)));
     HIP_TRY(ctx->totals.ensure(sizeof(Totals)));
     ctx->capacity = paths;
     return RT_OK;
@@ -135,6 +136,12 @@ int rt_context_create(int device_id, rt_context** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
+    // one segment per wave slot of the chip: 4 SIMDs x 8 waves per CU
+    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 32u;
+    if (const char* e = std::getenv("RT_WAVE_TARGET")) {
+        const long v = std::atol(e);
+        if (v > 0) ctx->wave_target = (uint32_t)v;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     *out = ctx.release();
     return RT_OK;
@@ -345,7 +352,6 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     rb.hits = ctx->hits.p;
     for (int k = 0; k < 3; k++) rb.queue[k] = (uint32_t*)ctx->queue[k].p;
     rb.Lbuf = ctx->lbuf.p;
-    rb.ctl = (BatchCtl*)ctx->ctl.p;
     rb.totals = (Totals*)ctx->totals.p;
     rb.capacity = ctx->capacity;
     const LaunchCfg cfg = ctx->cfg();
@@ -396,10 +402,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin + s0;
             g.n_samples = std::min(samples_per_batch, n_samples - s0);
-            g.padded = (rw % 8 != 0 || rh % 8 != 0) ? 1u : 0u;
-            const uint32_t n_upper = g.n_pix_slots * g.n_samples;
-
-            HIP_TRY(hipMemsetAsync(ctx->ctl.p, 0, sizeof(BatchCtl), st));
+            g.n_slots = g.n_pix_slots * g.n_samples;
+            // segments: one per wave, a multiple of 64 slots long
+            g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + cfg.wave_target - 1) / cfg.wave_target + 63u) / 64u * 64u);
+            g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
+            HIP_TRY(ctx->segcnt.ensure((size_t)(MAX_DEPTH + 1) * g.n_seg * sizeof(uint32_t)));
+            HIP_TRY(ctx->qcnt.ensure((size_t)3 * g.n_seg * sizeof(uint32_t)));
+            rb.segcnt = (uint32_t*)ctx->segcnt.p;
+            rb.qcnt = (uint32_t*)ctx->qcnt.p;
             auto bind = [&]() {
                 rb.cur = RayBuffers{ctx->rayA[cur].p, ctx->rayB[cur].p, ctx->rayC[cur].p};
                 rb.next = RayBuffers{ctx->rayA[cur ^ 1].p, ctx->rayB[cur ^ 1].p, ctx->rayC[cur ^ 1].p};
@@ -409,17 +419,12 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             for (uint32_t d = 0; d < p->max_bounces; d++) {
                 const bool last = d + 1 == p->max_bounces;
                 int lr = mark(0, [&]() {
-                    return launch_trace(cfg, s->dev, rb, d, last, n_upper, p->t_min, p->sky_intensity, count);
+                    return launch_trace(cfg, s->dev, g, rb, d, last, p->t_min, p->sky_intensity, count);
                 });
                 if (lr) return fail(RT_ERR_DEVICE, "trace launch failed");
                 trace_launches++;
                 if (last) break;
-                lr = mark(1, [&]() {
-                    for (uint32_t k = 0; k < 3; k++)
-                        if (s->dev.kinds_present & (1u << k))
-                            if (launch_shade(cfg, s->dev, rb, d, k, n_upper)) return -1;
-                    return 0;
-                });
+                lr = mark(1, [&]() { return launch_shade(cfg, s->dev, g, rb, d); });
                 if (lr) return fail(RT_ERR_DEVICE, "shade launch failed");
                 cur ^= 1;
                 bind();

@@ -1,12 +1,14 @@
 // HIP kernels of the wavefront path tracer (gfx950, wave64).
 //
-// Stages per batch of paths:  raygen -> [ trace -> shade(lambert|metal|dielectric) ] x depth
-//                             -> accumulate.
+// Stages per batch of paths:  raygen -> [ trace -> shade ] x depth -> accumulate.
 // trace   : closest hit over the flattened pre-order entry array; terminates paths that miss
 //           (sky), hit an emitter or reach the depth cap; queues the rest by material kind.
-// shade   : one launch per material kind over that kind's queue (material-sorted, so a wave
-//           runs one scatter routine); surviving rays are compacted into the next ray buffer
-//           with a wave ballot + lane prefix + one atomic per wave.
+// shade   : walks the lambert, metal and dielectric queues one after the other (material-sorted,
+//           so a wave runs one scatter routine at a time) and compacts the surviving rays
+//           into the next ray buffer.
+// Every wave owns one segment of the batch's path slots from raygen to the last bounce, so
+// queueing and compaction use only the wave's own ballot and lane prefix: no atomics, no
+// barriers, deterministic ray order.
 //
 // Intersection arithmetic must equal the reference's IEEE f32 results bit for bit, so this file
 // is built with -ffp-contract=off (no FMA), and relies on hipcc's default correctly rounded
@@ -19,7 +21,8 @@
 
 namespace rtamd {
 
-#define RT_BLOCK 256
+#define RT_BLOCK 256   // grid-stride kernels
+#define RT_WAVE 64     // segment kernels: one wave per workgroup
 
 struct Counts { uint32_t box, tri, sph; };
 
@@ -177,17 +180,17 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// wave-level compaction: ballot + lane prefix + one atomic per wave
+// wave-level compaction: ballot + lane prefix.  `count` is wave-uniform.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+__device__ __forceinline__ uint32_t lane_prefix(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+// position of this lane's element when the lanes with pred set append behind `count`
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t& count) {
     const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0u;
-    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    return base + prefix;
+    const uint32_t pos = count + lane_prefix(m);
+    count += (uint32_t)__popcll(m);
+    return pos;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -234,18 +237,19 @@ __device__ __forceinline__ bool slot_pixel(const BatchGeom& g, uint32_t q, uint3
 
 // ---------------------------------------------------------------------------------------------
 // raygen: the per-sample head of the tile loop (main.rs:362-364) + Camera::get_ray
-// (camera.rs:80-89).  Path slot = sample_in_batch * n_pix_slots + pixel_slot.
+// (camera.rs:80-89).  Wave s fills segment s with the camera rays of its path slots.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RT_BLOCK)
+__global__ void __launch_bounds__(RT_WAVE)
 k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
-         float4* __restrict__ B, float4* __restrict__ C, BatchCtl* ctl) {
-    const uint32_t total = g.n_pix_slots * g.n_samples;
+         float4* __restrict__ B, float4* __restrict__ C, uint32_t* __restrict__ segcnt) {
+    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t base = seg * g.seg_len;
     const float inv_w = 1.0f / (float)(g.width - 1u);      // main.rs:330-331
     const float inv_h = 1.0f / (float)(g.height - 1u);
-    // trip count is uniform per wave so that every lane reaches the ballot in wave_append
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < total; base += gridDim.x * RT_BLOCK) {
-        const uint32_t s = base + threadIdx.x;
-        bool valid = s < total;
+    uint32_t out = 0;
+    for (uint32_t j0 = 0; j0 < g.seg_len; j0 += 64u) {
+        const uint32_t s = base + j0 + lane;
+        bool valid = s < g.n_slots;
         uint32_t x = 0, y = 0;
         const uint32_t k = s / g.n_pix_slots, q = s - k * g.n_pix_slots;
         valid = valid && slot_pixel(g, q, x, y);
@@ -274,29 +278,32 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
             b.w = u2f(klo);
             c = make_float4(1.0f, 1.0f, 1.0f, u2f(khi));
         }
-        uint32_t pos = s;
-        if (g.padded) pos = wave_append(valid, &ctl->ray_count[0]);
+        const uint32_t pos = base + wave_append(valid, out);
         if (valid) { A[pos] = a; B[pos] = b; C[pos] = c; }
     }
-    if (!g.padded && blockIdx.x == 0 && threadIdx.x == 0) ctl->ray_count[0] = total;
+    if (lane == 0) segcnt[seg] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace: closest hit for every live ray of this depth, terminate or queue
+// trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
 // ---------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(RT_BLOCK)
-k_trace(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
+__global__ void __launch_bounds__(RT_WAVE)
+k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
-        uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf, BatchCtl* ctl,
-        Totals* totals, uint32_t depth, uint32_t last_depth, float t_min, float sky_intensity) {
+        uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf,
+        const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ qcnt, Totals* totals,
+        uint32_t last_depth, float t_min, float sky_intensity) {
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
-    const uint32_t n = ctl->ray_count[depth];
+    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t base = seg * g.seg_len;
+    const uint32_t n = segcnt[seg];
+    uint32_t n0 = 0, n1 = 0, n2 = 0;
     Counts cnt{0, 0, 0};
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+        const uint32_t i = base + j0 + lane;
+        const bool valid = j0 + lane < n;
         uint32_t kind = 7u;                                // 7 = nothing to queue
         if (valid) {
             const float4 a = A[i], b = B[i];
@@ -328,12 +335,17 @@ k_trace(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
             }
         }
         uint32_t pos;
-        pos = wave_append(kind == 0u, &ctl->qcount[depth][0]);
-        if (kind == 0u) q0[pos] = i;
-        pos = wave_append(kind == 1u, &ctl->qcount[depth][1]);
-        if (kind == 1u) q1[pos] = i;
-        pos = wave_append(kind == 2u, &ctl->qcount[depth][2]);
-        if (kind == 2u) q2[pos] = i;
+        pos = wave_append(kind == 0u, n0);
+        if (kind == 0u) q0[base + pos] = i;
+        pos = wave_append(kind == 1u, n1);
+        if (kind == 1u) q1[base + pos] = i;
+        pos = wave_append(kind == 2u, n2);
+        if (kind == 2u) q2[base + pos] = i;
+    }
+    if (lane == 0) {
+        qcnt[seg] = n0;
+        qcnt[g.n_seg + seg] = n1;
+        qcnt[2u * g.n_seg + seg] = n2;
     }
     if (COUNT) {
         atomicAdd(&totals->box, (unsigned long long)cnt.box);
@@ -343,26 +355,25 @@ k_trace(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
 }
 
 // ---------------------------------------------------------------------------------------------
-// shade: Material::scatter (material.rs) for one kind; compacts survivors into the next buffer
+// shade: Material::scatter (material.rs) -- one material kind at a time over the wave's queues;
+// survivors are compacted into the wave's segment of the next ray buffer
 // ---------------------------------------------------------------------------------------------
 template <int KIND>
-__global__ void __launch_bounds__(RT_BLOCK)
-k_shade(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
-        const float4* __restrict__ C, const uint2* __restrict__ hits, const uint32_t* __restrict__ queue,
-        float4* __restrict__ nA, float4* __restrict__ nB, float4* __restrict__ nC,
-        float4* __restrict__ Lbuf, BatchCtl* ctl, uint32_t depth) {
+__device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __restrict__ A,
+                                            const float4* __restrict__ B, const float4* __restrict__ C,
+                                            const uint2* __restrict__ hits, const uint32_t* __restrict__ queue,
+                                            float4* __restrict__ nA, float4* __restrict__ nB,
+                                            float4* __restrict__ nC, float4* __restrict__ Lbuf, uint32_t base,
+                                            uint32_t n, uint32_t ctr, uint32_t lane, uint32_t& out) {
     const float4* geo = (const float4*)sc.prim_geo;
     const float4* mats = (const float4*)sc.materials;
-    const uint32_t n = ctl->qcount[depth][KIND];
-    const uint32_t ctr = depth * 16u;
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-        const uint32_t j = base + threadIdx.x;
-        const bool valid = j < n;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+        const bool valid = j0 + lane < n;
         bool alive = false;
         float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
         uint32_t slot = 0;
         if (valid) {
-            const uint32_t i = queue[j];
+            const uint32_t i = queue[base + j0 + lane];
             const float4 a = A[i], b = B[i], c = C[i];
             const uint2 h = hits[i];
             const float t = u2f(h.x);
@@ -433,19 +444,38 @@ k_shade(DevScene sc, const float4* __restrict__ A, const float4* __restrict__ B,
             nb = make_float4(ddx, ddy, ddz, b.w);
             nc = make_float4(c.x * ar, c.y * ag, c.z * ab, c.w);
         }
-        const uint32_t pos = wave_append(alive, &ctl->ray_count[depth + 1]);
+        const uint32_t pos = base + wave_append(alive, out);
         if (alive) { nA[pos] = na; nB[pos] = nb; nC[pos] = nc; }
         else if (valid) Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // scatter() == false: emitted only
     }
 }
 
+__global__ void __launch_bounds__(RT_WAVE)
+k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
+        const float4* __restrict__ C, const uint2* __restrict__ hits, const uint32_t* __restrict__ q0,
+        const uint32_t* __restrict__ q1, const uint32_t* __restrict__ q2, float4* __restrict__ nA,
+        float4* __restrict__ nB, float4* __restrict__ nC, float4* __restrict__ Lbuf,
+        const uint32_t* __restrict__ qcnt, uint32_t* __restrict__ segcnt_next, uint32_t depth) {
+    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t base = seg * g.seg_len;
+    const uint32_t ctr = depth * 16u;
+    uint32_t out = 0;
+    if (sc.kinds_present & 1u)
+        shade_queue<RT_MAT_LAMBERT>(sc, A, B, C, hits, q0, nA, nB, nC, Lbuf, base, qcnt[seg], ctr, lane, out);
+    if (sc.kinds_present & 2u)
+        shade_queue<RT_MAT_METAL>(sc, A, B, C, hits, q1, nA, nB, nC, Lbuf, base, qcnt[g.n_seg + seg], ctr, lane, out);
+    if (sc.kinds_present & 4u)
+        shade_queue<RT_MAT_DIELECTRIC>(sc, A, B, C, hits, q2, nA, nB, nC, Lbuf, base, qcnt[2u * g.n_seg + seg], ctr,
+                                       lane, out);
+    if (lane == 0) segcnt_next[seg] = out;
+}
+
 // ---------------------------------------------------------------------------------------------
 // accumulate: per pixel, add the batch's samples in sample order (one owner per pixel: no
-// atomics, fixed summation order).  Thread 0 also folds the batch's ray counts into the totals.
+// atomics, fixed summation order).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(RT_BLOCK)
-k_accumulate(BatchGeom g, const float4* __restrict__ Lbuf, float* __restrict__ accum, const BatchCtl* ctl,
-             Totals* totals, uint32_t max_bounces) {
+k_accumulate(BatchGeom g, const float4* __restrict__ Lbuf, float* __restrict__ accum) {
     for (uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x; q < g.n_pix_slots; q += gridDim.x * RT_BLOCK) {
         uint32_t x, y;
         if (!slot_pixel(g, q, x, y)) continue;
@@ -457,10 +487,21 @@ k_accumulate(BatchGeom g, const float4* __restrict__ Lbuf, float* __restrict__ a
         float* dst = accum + ((size_t)y * g.width + x) * 3;
         dst[0] += r; dst[1] += gg; dst[2] += b;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long rays = 0;
-        for (uint32_t d = 0; d < max_bounces; d++) rays += ctl->ray_count[d];
-        totals->rays += rays;
+}
+
+// rays traced by the batch = sum of the live-ray counts of every segment at every depth
+__global__ void __launch_bounds__(RT_BLOCK)
+k_count_rays(const uint32_t* __restrict__ segcnt, uint32_t n, Totals* totals) {
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK) s += segcnt[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    __shared__ unsigned long long part[RT_BLOCK / 64];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < RT_BLOCK / 64; k++) t += part[k];
+        totals->rays += t;
     }
 }
 
@@ -510,44 +551,36 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
 int launch_raygen(const LaunchCfg& cfg, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
                   const RenderBuffers& rb) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const size_t total = (size_t)g.n_pix_slots * g.n_samples;
-    hipLaunchKernelGGL(k_raygen, dim3(grid_for(total, cfg.grid_cap)), dim3(RT_BLOCK), 0, st, cam, g,
-                       (uint32_t)seed, (uint32_t)(seed >> 32), (float4*)rb.cur.A, (float4*)rb.cur.B,
-                       (float4*)rb.cur.C, rb.ctl);
+    hipLaunchKernelGGL(k_raygen, dim3(g.n_seg), dim3(RT_WAVE), 0, st, cam, g, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (float4*)rb.cur.A, (float4*)rb.cur.B, (float4*)rb.cur.C, rb.segcnt);
     return check_launch();
 }
 
-int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const RenderBuffers& rb, uint32_t depth,
-                 bool last_depth, uint32_t n_upper, float t_min, float sky_intensity, bool count) {
+int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
+                 uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const uint32_t grid = grid_for(n_upper, cfg.grid_cap);
+    const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
     if (count)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,
+        hipLaunchKernelGGL(k_trace<true>, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
                            (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
-                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, rb.ctl, rb.totals, depth,
+                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,
                            last_depth ? 1u : 0u, t_min, sky_intensity);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,
+        hipLaunchKernelGGL(k_trace<false>, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
                            (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
-                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, rb.ctl, rb.totals, depth,
+                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,
                            last_depth ? 1u : 0u, t_min, sky_intensity);
     return check_launch();
 }
 
-int launch_shade(const LaunchCfg& cfg, const DevScene& sc, const RenderBuffers& rb, uint32_t depth,
-                 uint32_t kind, uint32_t n_upper) {
+int launch_shade(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
+                 uint32_t depth) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const uint32_t grid = grid_for(n_upper, cfg.grid_cap);
-#define RT_SHADE(K)                                                                                     \
-    hipLaunchKernelGGL(k_shade<K>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float4*)rb.cur.A,      \
-                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (const uint2*)rb.hits,         \
-                       (const uint32_t*)rb.queue[K], (float4*)rb.next.A, (float4*)rb.next.B,            \
-                       (float4*)rb.next.C, (float4*)rb.Lbuf, rb.ctl, depth)
-    if (kind == RT_MAT_LAMBERT) RT_SHADE(0);
-    else if (kind == RT_MAT_METAL) RT_SHADE(1);
-    else if (kind == RT_MAT_DIELECTRIC) RT_SHADE(2);
-    else return -1;
-#undef RT_SHADE
+    hipLaunchKernelGGL(k_shade, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
+                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (const uint2*)rb.hits,
+                       (const uint32_t*)rb.queue[0], (const uint32_t*)rb.queue[1], (const uint32_t*)rb.queue[2],
+                       (float4*)rb.next.A, (float4*)rb.next.B, (float4*)rb.next.C, (float4*)rb.Lbuf,
+                       (const uint32_t*)rb.qcnt, rb.segcnt + (size_t)(depth + 1) * g.n_seg, depth);
     return check_launch();
 }
 
@@ -555,7 +588,9 @@ int launch_accumulate(const LaunchCfg& cfg, const BatchGeom& g, const RenderBuff
                       uint32_t max_bounces) {
     hipStream_t st = (hipStream_t)cfg.stream;
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(g.n_pix_slots, cfg.grid_cap)), dim3(RT_BLOCK), 0, st, g,
-                       (const float4*)rb.Lbuf, (float*)d_accum, (const BatchCtl*)rb.ctl, rb.totals, max_bounces);
+                       (const float4*)rb.Lbuf, (float*)d_accum);
+    hipLaunchKernelGGL(k_count_rays, dim3(1), dim3(RT_BLOCK), 0, st, (const uint32_t*)rb.segcnt,
+                       max_bounces * g.n_seg, rb.totals);
     return check_launch();
 }
 

@@ -74,19 +74,20 @@ struct DevScene {
 
 constexpr uint32_t MAX_DEPTH = 64;
 
-// Per-batch control block in device memory (zeroed before every batch).
-struct BatchCtl {
-    uint32_t ray_count[MAX_DEPTH + 1];   // live rays entering depth d
-    uint32_t qcount[MAX_DEPTH][4];       // rays queued for the shade kernel of kind k at depth d
-};
-
 // Totals in device memory, read back once per render call.
 struct Totals {
     unsigned long long rays, box, tri, sph;
 };
 
 // One wavefront batch: pixels [pix_base, pix_base + n_pix_slots) of the rectangle in 8x8-tile
-// order, samples [sample_base, sample_base + n_samples).
+// order, samples [sample_base, sample_base + n_samples).  Path slot = sample * n_pix_slots + pixel.
+//
+// The batch's path slots are cut into n_seg segments of seg_len slots (a multiple of 64) and
+// every segment is owned by ONE wave for the whole batch: that wave generates the segment's
+// camera rays, traces them, shades them and compacts the survivors back into the same
+// segment of the other ray buffer.  Compaction therefore needs only the wave's own ballot and
+// lane prefix -- no atomics, no barriers, no cross-wave traffic -- and the order of rays in a
+// segment is deterministic.  segcnt[d * n_seg + s] = live rays of segment s entering depth d.
 struct BatchGeom {
     uint32_t width, height;       // full frame
     uint32_t x0, y0, x1, y1;      // rectangle
@@ -94,7 +95,8 @@ struct BatchGeom {
     uint32_t tile_base;           // first tile of this batch
     uint32_t n_pix_slots;         // 64 * tiles in this batch
     uint32_t sample_base, n_samples;
-    uint32_t padded;              // some slots fall outside the rectangle
+    uint32_t n_slots;             // n_pix_slots * n_samples
+    uint32_t n_seg, seg_len;
 };
 
 struct RayBuffers {
@@ -106,26 +108,27 @@ struct RayBuffers {
 struct RenderBuffers {
     RayBuffers cur, next;
     void* hits;            // uint2 per ray: t bits, prim id | PRIM_BACKFACE
-    uint32_t* queue[3];    // ray indices per scattering material kind
+    uint32_t* queue[3];    // ray indices per scattering material kind, segment-local
     void* Lbuf;            // float4 per path slot: the path's radiance
-    BatchCtl* ctl;
+    uint32_t* segcnt;      // [(MAX_DEPTH + 1) * n_seg]
+    uint32_t* qcnt;        // [3 * n_seg] queue lengths of the current depth
     Totals* totals;
     size_t capacity;       // paths
 };
 
 struct LaunchCfg {
     void* stream;          // hipStream_t
-    uint32_t grid_cap;     // upper bound on blocks per launch
+    uint32_t grid_cap;     // upper bound on blocks per launch (grid-stride kernels)
+    uint32_t wave_target;  // segments (waves) a full-size batch is cut into
 };
 
 // kernels' host-side launchers (rt_device.hip)
 int launch_trace_api(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min,
                      float t_max, void* d_hits, Totals* d_counts, bool count);
 int launch_raygen(const LaunchCfg&, const rt_camera&, const BatchGeom&, uint64_t seed, const RenderBuffers&);
-int launch_trace(const LaunchCfg&, const DevScene&, const RenderBuffers&, uint32_t depth, bool last_depth,
-                 uint32_t n_upper, float t_min, float sky_intensity, bool count);
-int launch_shade(const LaunchCfg&, const DevScene&, const RenderBuffers&, uint32_t depth, uint32_t kind,
-                 uint32_t n_upper);
+int launch_trace(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
+                 bool last_depth, float t_min, float sky_intensity, bool count);
+int launch_shade(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth);
 int launch_accumulate(const LaunchCfg&, const BatchGeom&, const RenderBuffers&, void* d_accum,
                       uint32_t max_bounces);
 int launch_tonemap(const LaunchCfg&, const void* d_accum, uint32_t spp, void* d_out, size_t npix);
