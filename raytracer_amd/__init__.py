@@ -25,6 +25,7 @@ ASSET_DIR = os.path.join(_HERE, "assets")
 MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
+TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP = 0, 1, 2
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS = 1, 2
 DEFAULT_SEED = 0x9E3779B97F4A7C15
@@ -81,6 +82,7 @@ def _load():
         "rt_scene_add_spheres": (i32, [vp, vp, sz]),
         "rt_scene_add_mesh": (i32, [vp, vp, sz, vp]),
         "rt_scene_set_root": (i32, [vp, i32]),
+        "rt_scene_set_traversal": (i32, [vp, i32]),
         "rt_scene_commit": (i32, [vp]),
         "rt_scene_num_prims": (sz, [vp]),
         "rt_scene_num_entries": (sz, [vp]),
@@ -122,7 +124,7 @@ lib = _load()
 ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_context_stream",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
-    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_commit",
+    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_traversal", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_trace",
     "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
@@ -224,6 +226,9 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    def set_traversal(self, mode):
+        _check(lib.rt_scene_set_traversal(self.h, mode))
 
     @property
     def num_prims(self):

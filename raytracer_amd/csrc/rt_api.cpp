@@ -77,6 +77,7 @@ struct rt_scene {
     std::vector<rt_material> mats;
     std::vector<SceneObject> objects;
     int root_kind = RT_ROOT_BVH;
+    int traversal = RT_TRAVERSAL_AUTO;
     bool committed = false;
     FlatScene flat;
     DeviceBuffer d_entries, d_geo, d_meta, d_mats;
@@ -223,6 +224,16 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
     return RT_OK;
 }
 
+int rt_scene_set_traversal(rt_scene* s, int mode) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
+    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_SWEEP) return fail(RT_ERR_INVALID, "unknown traversal mode");
+    s->traversal = mode;
+    if (s->committed)
+        s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
+                       (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
+    return RT_OK;
+}
+
 int rt_scene_commit(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
@@ -256,6 +267,8 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_prims = (uint32_t)f.n_prims();
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
+    s->dev.sweep = s->traversal == RT_TRAVERSAL_SWEEP ||
+                   (s->traversal == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     // the host copies of the geometry are no longer needed
     for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
     s->flat.entries.clear(); s->flat.entries.shrink_to_fit();

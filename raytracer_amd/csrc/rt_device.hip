@@ -132,21 +132,128 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
 }
 
 // ---------------------------------------------------------------------------------------------
+// Closest hit, wave-synchronous form for small scenes.  Skip links only point forward, so a
+// wave can sweep the entry array ONCE in order: entry e is fetched with scalar loads into
+// SGPRs (one fetch per wave instead of one per lane, and a wave-uniform branch on its type) and
+// the lanes whose own cursor stands at e test it.  Every lane still visits exactly the entries,
+// in exactly the order and with exactly the best_t, of the per-lane walk above, so results are
+// bit-identical; lanes whose cursor is elsewhere idle for that entry.  Must be called with the
+// whole wave converged; lanes without a ray pass valid = false.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(4)))* const_f4_ptr;
+
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent_, uint32_t n_ent, bool valid,
+                                                  float ox, float oy, float oz, float dx, float dy, float dz,
+                                                  float t_min, float& best_t, uint32_t& best_prim,
+                                                  uint32_t& best_mk, Counts& cnt) {
+    const const_f4_ptr ent = (const_f4_ptr)(uintptr_t)ent_;
+    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const float EPS = 1.1920929e-7f;
+    best_prim = RT_MISS;
+    best_mk = 0;
+    uint32_t cursor = valid ? 0u : n_ent;
+    for (uint32_t e = 0; e < n_ent; e++) {
+        const bool on = cursor == e;
+        if (__ballot(on) == 0ull) continue;
+        const f32x4 a = ent[3 * e];
+        const f32x4 b = ent[3 * e + 1];
+        const uint32_t w = f2u(a.w);
+        const uint32_t tag = w >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            if (COUNT) cnt.box += on ? 1u : 0u;
+            float t0 = (a.x - ox) * ix, t1 = (b.x - ox) * ix;
+            float lo = ix < 0.0f ? t1 : t0, hi = ix < 0.0f ? t0 : t1;
+            float tmn = lo > t_min ? lo : t_min;
+            float tmx = hi < best_t ? hi : best_t;
+            bool miss = tmx <= tmn;
+            t0 = (a.y - oy) * iy; t1 = (b.y - oy) * iy;
+            lo = iy < 0.0f ? t1 : t0; hi = iy < 0.0f ? t0 : t1;
+            tmn = lo > tmn ? lo : tmn;
+            tmx = hi < tmx ? hi : tmx;
+            miss = miss || (tmx <= tmn);
+            t0 = (a.z - oz) * iz; t1 = (b.z - oz) * iz;
+            lo = iz < 0.0f ? t1 : t0; hi = iz < 0.0f ? t0 : t1;
+            tmn = lo > tmn ? lo : tmn;
+            tmx = hi < tmx ? hi : tmx;
+            miss = miss || (tmx <= tmn);
+            const uint32_t nxt = miss ? (w & SKIP_MASK) : e + 1u;
+            cursor = on ? nxt : cursor;
+        } else if (tag == TAG_TRI) {
+            if (COUNT) cnt.tri += on ? 1u : 0u;
+            const f32x4 c = ent[3 * e + 2];
+            const float px = dy * c.z - dz * c.y;
+            const float py = dz * c.x - dx * c.z;
+            const float pz = dx * c.y - dy * c.x;
+            const float det = dot3(b.x, b.y, b.z, px, py, pz);
+            const float inv_det = 1.0f / det;
+            const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+            const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+            const float qx = ty * b.z - tz * b.y;
+            const float qy = tz * b.x - tx * b.z;
+            const float qz = tx * b.y - ty * b.x;
+            const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+            const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
+            // the reference's early returns, evaluated in its order
+            const bool hit = on && !(fabsf(det) < EPS) && !(u < 0.0f || u > 1.0f) &&
+                             !(v < 0.0f || u + v > 1.0f) && (t >= t_min && t < best_t);
+            if (hit) {
+                best_t = t;
+                best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
+                best_mk = f2u(c.w);
+            }
+            cursor = on ? e + 1u : cursor;
+        } else {
+            if (COUNT) cnt.sph += on ? 1u : 0u;
+            const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
+            const float qa = dot3(dx, dy, dz, dx, dy, dz);
+            const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
+            const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
+            const float disc = half_b * half_b - qa * qc;
+            if (on && !(disc < 0.0f)) {
+                const float sqrtd = sqrtf(disc);
+                float root = (-half_b - sqrtd) / qa;
+                bool ok = true;
+                if (root < t_min || best_t < root) {
+                    root = (-half_b + sqrtd) / qa;
+                    if (root < t_min || best_t < root) ok = false;
+                }
+                if (ok) {
+                    best_t = root;
+                    best_prim = f2u(b.w);
+                    best_mk = f2u(b.y);
+                }
+            }
+            cursor = on ? e + 1u : cursor;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // rt_trace: AoS rays in, full hit records out (the hit-parity surface)
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
             rt_hit* __restrict__ out, Totals* totals) {
     const float4* ent = (const float4*)sc.entries;
     const float4* geo = (const float4*)sc.prim_geo;
     Counts cnt{0, 0, 0};
-    for (size_t r = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (size_t)gridDim.x * RT_BLOCK) {
-        const float ox = rays[r * 6 + 0], oy = rays[r * 6 + 1], oz = rays[r * 6 + 2];
-        const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+    // the trip count is the same for every lane of a wave (the sweep needs the wave converged)
+    for (size_t r0 = (size_t)blockIdx.x * RT_BLOCK; r0 < n; r0 += (size_t)gridDim.x * RT_BLOCK) {
+        const size_t r = r0 + threadIdx.x;
+        const bool valid = r < n;
+        float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1;
+        if (valid) {
+            ox = rays[r * 6 + 0]; oy = rays[r * 6 + 1]; oz = rays[r * 6 + 2];
+            dx = rays[r * 6 + 3]; dy = rays[r * 6 + 4]; dz = rays[r * 6 + 5];
+        }
         float t = t_max;
-        uint32_t prim, mk;
-        closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
+        uint32_t prim = RT_MISS, mk = 0;
+        if (SWEEP) closest_hit_sweep<COUNT>(ent, sc.n_entries, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
+        else if (valid) closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
+        if (!valid) continue;
         rt_hit h;
         if (prim == RT_MISS) {
             h.t = 0.0f; h.prim_id = RT_MISS;
@@ -287,7 +394,7 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
 // ---------------------------------------------------------------------------------------------
 // trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool SWEEP>
 __global__ void __launch_bounds__(RT_WAVE)
 k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -305,11 +412,13 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         const uint32_t i = base + j0 + lane;
         const bool valid = j0 + lane < n;
         uint32_t kind = 7u;                                // 7 = nothing to queue
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        if (valid) { a = A[i]; b = B[i]; }
+        float t = __builtin_inff();                        // main.rs:46: t_max = f32::INFINITY
+        uint32_t prim = RT_MISS, mk = 0;
+        if (SWEEP) closest_hit_sweep<COUNT>(ent, sc.n_entries, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
+        else if (valid) closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
         if (valid) {
-            const float4 a = A[i], b = B[i];
-            float t = __builtin_inff();                    // main.rs:46: t_max = f32::INFINITY
-            uint32_t prim, mk;
-            closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
             const uint32_t slot = f2u(a.w);
             if (prim == RT_MISS) {
                 // sky_color (main.rs:31-38): gradient on the y of the normalised direction
@@ -539,12 +648,12 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t grid = grid_for(n, cfg.grid_cap);
-    if (count)
-        hipLaunchKernelGGL(k_trace_api<true>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n,
-                           t_min, t_max, (rt_hit*)d_hits, d_counts);
-    else
-        hipLaunchKernelGGL(k_trace_api<false>, dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n,
-                           t_min, t_max, (rt_hit*)d_hits, d_counts);
+#define RT_TRACE_API(CNT, SWP)                                                                          \
+    hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n, \
+                       t_min, t_max, (rt_hit*)d_hits, d_counts)
+    if (sc.sweep) { if (count) RT_TRACE_API(true, true); else RT_TRACE_API(false, true); }
+    else { if (count) RT_TRACE_API(true, false); else RT_TRACE_API(false, false); }
+#undef RT_TRACE_API
     return check_launch();
 }
 
@@ -560,16 +669,14 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
                  uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
-    if (count)
-        hipLaunchKernelGGL(k_trace<true>, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
-                           (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
-                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,
-                           last_depth ? 1u : 0u, t_min, sky_intensity);
-    else
-        hipLaunchKernelGGL(k_trace<false>, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
-                           (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],
-                           rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,
-                           last_depth ? 1u : 0u, t_min, sky_intensity);
+#define RT_TRACE(CNT, SWP)                                                                              \
+    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A, \
+                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
+                       rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
+                       last_depth ? 1u : 0u, t_min, sky_intensity)
+    if (sc.sweep) { if (count) RT_TRACE(true, true); else RT_TRACE(false, true); }
+    else { if (count) RT_TRACE(true, false); else RT_TRACE(false, false); }
+#undef RT_TRACE
     return check_launch();
 }
 

@@ -70,7 +70,11 @@ struct DevScene {
     uint32_t n_prims;
     uint32_t n_mats;
     uint32_t kinds_present;
+    uint32_t sweep;           // 1: wave-synchronous sweep of the entry array, 0: per-lane walk
 };
+
+// scenes with at most this many entries are traced with the wave-synchronous sweep by default
+constexpr uint32_t SWEEP_MAX_ENTRIES = 192;
 
 constexpr uint32_t MAX_DEPTH = 64;
 

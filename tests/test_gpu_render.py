@@ -87,6 +87,21 @@ def test_deterministic_and_partition_invariant(rt, ob, ctx):
     assert not np.array_equal(other, full)
 
 
+def test_traversal_modes_render_identical_images(rt, ob, ctx):
+    """Per-lane walk and wave sweep give bit-identical hits, hence bit-identical images."""
+    osc = ob.Scene.world2(asset("thing.obj"), 1)
+    sc = mirror(rt, ctx, osc)
+    cam = product_camera(rt, osc, 96, 64)
+    imgs = []
+    for mode in (rt.TRAVERSAL_PER_LANE, rt.TRAVERSAL_SWEEP):
+        sc.set_traversal(mode)
+        img, st = sc.render(cam, rt.Scene.params(96, 64, 8, 6, osc.sky, flags=rt.RENDER_COUNT_VISITS))
+        imgs.append((img, st))
+    assert np.array_equal(imgs[0][0].view(np.uint32), imgs[1][0].view(np.uint32))
+    for k in ("rays_traced", "box_tests", "tri_tests", "sph_tests"):
+        assert imgs[0][1][k] == imgs[1][1][k]
+
+
 def test_depth_one_and_counts(rt, ob, ctx):
     osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
     sc = mirror(rt, ctx, osc)

@@ -13,14 +13,25 @@ def _scene_pair(rt, ctx, oscene):
     return oscene, mirror(rt, ctx, oscene)
 
 
+def _check_all_modes(rt, sc, rays, want, t_min=0.001, t_max=np.inf, sweep_limit=60000):
+    """Both traversal forms of the kernel (per-lane walk, wave-synchronous sweep) must give the
+    oracle's hits.  The sweep costs O(entries) per wave, so on big scenes it gets fewer rays."""
+    sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+    assert_hits_equal(sc.trace(rays, t_min, t_max), want)
+    n = len(rays) if sc.num_entries <= 4096 else min(len(rays), sweep_limit)
+    sc.set_traversal(rt.TRAVERSAL_SWEEP)
+    assert_hits_equal(sc.trace(rays[:n], t_min, t_max), want[:n])
+    sc.set_traversal(rt.TRAVERSAL_AUTO)
+    assert_hits_equal(sc.trace(rays[:4096], t_min, t_max), want[:4096])
+
+
 @pytest.mark.parametrize("name", ["cornell_box_plane.obj", "cornell_box.obj"])
 def test_cornell_camera_and_bounce_rays(rt, ob, ctx, name):
     osc, sc = _scene_pair(rt, ctx, ob.Scene.cornell_box(asset(name)))
     rays = osc.record_rays(96, 96, 4, 8, cap=200000, stride=1)
     assert len(rays) > 50000
     want, _ = osc.trace(rays)
-    got = sc.trace(rays)
-    assert_hits_equal(got, want)
+    _check_all_modes(rt, sc, rays, want)
     assert (want["prim_id"] != ob.MISS).mean() > 0.5
 
 
@@ -28,10 +39,10 @@ def test_world1_spheres(rt, ob, ctx):
     osc, sc = _scene_pair(rt, ctx, ob.Scene.world1())
     rays = osc.record_rays(160, 90, 4, 6, cap=200000)
     want, _ = osc.trace(rays)
-    assert_hits_equal(sc.trace(rays), want)
+    _check_all_modes(rt, sc, rays, want)
     rr = random_rays(ob, 3, 100000, -6.0, 6.0)
     want, _ = osc.trace(rr)
-    assert_hits_equal(sc.trace(rr), want)
+    _check_all_modes(rt, sc, rr, want)
 
 
 @pytest.mark.parametrize("variant", [0, 1])
@@ -39,7 +50,7 @@ def test_world2_mesh_plus_sphere(rt, ob, ctx, variant):
     osc, sc = _scene_pair(rt, ctx, ob.Scene.world2(asset("thing.obj"), variant))
     rays = osc.record_rays(96, 96, 4, 6, cap=200000)
     want, _ = osc.trace(rays)
-    assert_hits_equal(sc.trace(rays), want)
+    _check_all_modes(rt, sc, rays, want)
 
 
 @pytest.mark.parametrize("root", [0, 2])
@@ -51,7 +62,7 @@ def test_random_scenes(rt, ob, ctx, seed, root):
     rays = random_rays(ob, seed + 10, 150000, -12.0, 12.0)
     for t_min, t_max in [(0.001, np.inf), (0.05, 1.0)]:
         want, _ = osc.trace(rays, t_min, t_max)
-        assert_hits_equal(sc.trace(rays, t_min, t_max), want)
+        _check_all_modes(rt, sc, rays, want, t_min, t_max)
 
 
 def test_degenerate_scenes(rt, ob, ctx):
@@ -76,7 +87,7 @@ def test_degenerate_scenes(rt, ob, ctx):
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
         want, _ = osc.trace(rays)
-        assert_hits_equal(sc.trace(rays), want)
+        _check_all_modes(rt, sc, rays, want)
 
 
 def test_ties_between_coincident_primitives(rt, ob, ctx):
@@ -98,7 +109,7 @@ def test_ties_between_coincident_primitives(rt, ob, ctx):
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
         want, _ = osc.trace(rays)
-        assert_hits_equal(sc.trace(rays), want)
+        _check_all_modes(rt, sc, rays, want)
 
 
 def test_visit_counters_match_oracle(rt, ob, ctx):
@@ -110,10 +121,14 @@ def test_visit_counters_match_oracle(rt, ob, ctx):
     d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 6)).cuda()
     d_hits = torch.zeros(len(rays) * 10, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    counts = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
-    assert counts == (st["box_tests"], st["tri_tests"], st["sph_tests"])
-    got = d_hits.cpu().numpy().view(rt.hit_dt)
-    assert_hits_equal(got, want)
+    for mode in (rt.TRAVERSAL_PER_LANE, rt.TRAVERSAL_SWEEP):
+        sc.set_traversal(mode)
+        d_hits.zero_()
+        torch.cuda.synchronize()
+        counts = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
+        assert counts == (st["box_tests"], st["tri_tests"], st["sph_tests"])
+        got = d_hits.cpu().numpy().view(rt.hit_dt)
+        assert_hits_equal(got, want)
 
 
 def test_empty_batch_and_errors(rt, ob, ctx):
