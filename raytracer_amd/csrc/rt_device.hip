@@ -22,7 +22,8 @@
 namespace rtamd {
 
 #define RT_BLOCK 256   // grid-stride kernels
-#define RT_WAVE 64     // segment kernels: one wave per workgroup
+#define RT_WAVE 256    // segment kernels: workgroup size (every wave owns one segment)
+#define RT_WPB (RT_WAVE / 64)
 
 struct Counts { uint32_t box, tri, sph; };
 
@@ -150,6 +151,7 @@ __device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent
                                                   uint32_t& best_mk, Counts& cnt) {
     const const_f4_ptr ent = (const_f4_ptr)(uintptr_t)ent_;
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+    const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;   // math.rs:155: swap when inv_d < 0
     const float EPS = 1.1920929e-7f;
     best_prim = RT_MISS;
     best_mk = 0;
@@ -163,22 +165,16 @@ __device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent
         const uint32_t tag = w >> TAG_SHIFT;
         if (tag == TAG_BOX) {
             if (COUNT) cnt.box += on ? 1u : 0u;
-            float t0 = (a.x - ox) * ix, t1 = (b.x - ox) * ix;
-            float lo = ix < 0.0f ? t1 : t0, hi = ix < 0.0f ? t0 : t1;
-            float tmn = lo > t_min ? lo : t_min;
-            float tmx = hi < best_t ? hi : best_t;
-            bool miss = tmx <= tmn;
-            t0 = (a.y - oy) * iy; t1 = (b.y - oy) * iy;
-            lo = iy < 0.0f ? t1 : t0; hi = iy < 0.0f ? t0 : t1;
-            tmn = lo > tmn ? lo : tmn;
-            tmx = hi < tmx ? hi : tmx;
-            miss = miss || (tmx <= tmn);
-            t0 = (a.z - oz) * iz; t1 = (b.z - oz) * iz;
-            lo = iz < 0.0f ? t1 : t0; hi = iz < 0.0f ? t0 : t1;
-            tmn = lo > tmn ? lo : tmn;
-            tmx = hi < tmx ? hi : tmx;
-            miss = miss || (tmx <= tmn);
-            const uint32_t nxt = miss ? (w & SKIP_MASK) : e + 1u;
+            // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
+            // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
+            // per-axis early return equals the one test after the third axis because t_min only
+            // grows and t_max only shrinks.
+            const float x0 = (a.x - ox) * ix, x1 = (b.x - ox) * ix;
+            const float y0 = (a.y - oy) * iy, y1 = (b.y - oy) * iy;
+            const float z0 = (a.z - oz) * iz, z1 = (b.z - oz) * iz;
+            const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
+            const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), best_t);
+            const uint32_t nxt = tmx <= tmn ? (w & SKIP_MASK) : e + 1u;
             cursor = on ? nxt : cursor;
         } else if (tag == TAG_TRI) {
             if (COUNT) cnt.tri += on ? 1u : 0u;
@@ -195,14 +191,12 @@ __device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent
             const float qz = tx * b.y - ty * b.x;
             const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
             const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-            // the reference's early returns, evaluated in its order
-            const bool hit = on && !(fabsf(det) < EPS) && !(u < 0.0f || u > 1.0f) &&
-                             !(v < 0.0f || u + v > 1.0f) && (t >= t_min && t < best_t);
-            if (hit) {
-                best_t = t;
-                best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
-                best_mk = f2u(c.w);
-            }
+            // the reference's early returns (shape.rs:428-445) and acceptance test (shape.rs:297)
+            const bool hit = on & !(fabsf(det) < EPS) & !(u < 0.0f) & !(u > 1.0f) & !(v < 0.0f) &
+                             !(u + v > 1.0f) & (t >= t_min) & (t < best_t);
+            best_t = hit ? t : best_t;
+            best_prim = hit ? (f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u)) : best_prim;
+            best_mk = hit ? f2u(c.w) : best_mk;
             cursor = on ? e + 1u : cursor;
         } else {
             if (COUNT) cnt.sph += on ? 1u : 0u;
@@ -211,20 +205,16 @@ __device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent
             const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
             const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
             const float disc = half_b * half_b - qa * qc;
-            if (on && !(disc < 0.0f)) {
-                const float sqrtd = sqrtf(disc);
-                float root = (-half_b - sqrtd) / qa;
-                bool ok = true;
-                if (root < t_min || best_t < root) {
-                    root = (-half_b + sqrtd) / qa;
-                    if (root < t_min || best_t < root) ok = false;
-                }
-                if (ok) {
-                    best_t = root;
-                    best_prim = f2u(b.w);
-                    best_mk = f2u(b.y);
-                }
-            }
+            const float sqrtd = sqrtf(disc);
+            const float r0 = (-half_b - sqrtd) / qa;
+            const float r1 = (-half_b + sqrtd) / qa;
+            const bool bad0 = (r0 < t_min) | (best_t < r0);      // shape.rs:32-36, closed interval
+            const bool bad1 = (r1 < t_min) | (best_t < r1);
+            const float root = bad0 ? r1 : r0;
+            const bool hit = on & !(disc < 0.0f) & !(bad0 & bad1);
+            best_t = hit ? root : best_t;
+            best_prim = hit ? f2u(b.w) : best_prim;
+            best_mk = hit ? f2u(b.y) : best_mk;
             cursor = on ? e + 1u : cursor;
         }
     }
@@ -349,7 +339,8 @@ __device__ __forceinline__ bool slot_pixel(const BatchGeom& g, uint32_t q, uint3
 __global__ void __launch_bounds__(RT_WAVE)
 k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
          float4* __restrict__ B, float4* __restrict__ C, uint32_t* __restrict__ segcnt) {
-    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
     const uint32_t base = seg * g.seg_len;
     const float inv_w = 1.0f / (float)(g.width - 1u);      // main.rs:330-331
     const float inv_h = 1.0f / (float)(g.height - 1u);
@@ -403,7 +394,8 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         uint32_t last_depth, float t_min, float sky_intensity) {
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
-    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
     const uint32_t base = seg * g.seg_len;
     const uint32_t n = segcnt[seg];
     uint32_t n0 = 0, n1 = 0, n2 = 0;
@@ -565,7 +557,8 @@ k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         const uint32_t* __restrict__ q1, const uint32_t* __restrict__ q2, float4* __restrict__ nA,
         float4* __restrict__ nB, float4* __restrict__ nC, float4* __restrict__ Lbuf,
         const uint32_t* __restrict__ qcnt, uint32_t* __restrict__ segcnt_next, uint32_t depth) {
-    const uint32_t seg = blockIdx.x, lane = threadIdx.x;
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
     const uint32_t base = seg * g.seg_len;
     const uint32_t ctr = depth * 16u;
     uint32_t out = 0;
@@ -660,7 +653,7 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
 int launch_raygen(const LaunchCfg& cfg, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
                   const RenderBuffers& rb) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    hipLaunchKernelGGL(k_raygen, dim3(g.n_seg), dim3(RT_WAVE), 0, st, cam, g, (uint32_t)seed,
+    hipLaunchKernelGGL(k_raygen, dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), 0, st, cam, g, (uint32_t)seed,
                        (uint32_t)(seed >> 32), (float4*)rb.cur.A, (float4*)rb.cur.B, (float4*)rb.cur.C, rb.segcnt);
     return check_launch();
 }
@@ -670,7 +663,7 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
 #define RT_TRACE(CNT, SWP)                                                                              \
-    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A, \
+    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A, \
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
                        rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
                        last_depth ? 1u : 0u, t_min, sky_intensity)
@@ -683,7 +676,7 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
 int launch_shade(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
                  uint32_t depth) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    hipLaunchKernelGGL(k_shade, dim3(g.n_seg), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
+    hipLaunchKernelGGL(k_shade, dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A,
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (const uint2*)rb.hits,
                        (const uint32_t*)rb.queue[0], (const uint32_t*)rb.queue[1], (const uint32_t*)rb.queue[2],
                        (float4*)rb.next.A, (float4*)rb.next.B, (float4*)rb.next.C, (float4*)rb.Lbuf,
