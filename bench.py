@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
+    ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep"], default="auto")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -110,6 +111,8 @@ def main():
     t0 = time.time()
     wld = make_world(ctx, kind)
     build_s = time.time() - t0
+    wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
+                             "sweep": rt.TRAVERSAL_SWEEP}[args.traversal])
     cam = wld.camera(width, height)
     rects, samples = partition(width, height, spp, world, rank)
     accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)

@@ -137,8 +137,9 @@ int rt_context_create(int device_id, rt_context** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
-    // one segment per wave slot of the chip: 4 SIMDs x 8 waves per CU
-    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 32u;
+    // four segments per wave slot of the chip (4 SIMDs x 8 waves per CU): segments differ in how
+    // long their paths live, and the surplus lets the dispatcher even that out
+    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 128u;
     if (const char* e = std::getenv("RT_WAVE_TARGET")) {
         const long v = std::atol(e);
         if (v > 0) ctx->wave_target = (uint32_t)v;
@@ -267,6 +268,7 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_prims = (uint32_t)f.n_prims();
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
+    s->dev.has_spheres = f.has_spheres ? 1u : 0u;
     s->dev.sweep = s->traversal == RT_TRAVERSAL_SWEEP ||
                    (s->traversal == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     // the host copies of the geometry are no longer needed

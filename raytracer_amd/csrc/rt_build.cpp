@@ -212,6 +212,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
             float* g = &out.prim_geo[(size_t)o.prim_base * 4];
             g[0] = o.sphere.c[0]; g[1] = o.sphere.c[1]; g[2] = o.sphere.c[2]; g[3] = o.sphere.r;
             out.prim_meta[o.prim_base] = o.sphere.mat | META_SPHERE;
+            out.has_spheres = true;
             out.kinds_present |= 1u << mats[o.sphere.mat].kind;
             Box bx;                            // Sphere::get_aabb, shape.rs:47-52
             for (int k = 0; k < 3; k++) { bx.lo[k] = o.sphere.c[k] - o.sphere.r; bx.hi[k] = o.sphere.c[k] + o.sphere.r; }

@@ -144,130 +144,207 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef const f32x4 __attribute__((address_space(4)))* const_f4_ptr;
 
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit_sweep(const float4* __restrict__ ent_, uint32_t n_ent, bool valid,
-                                                  float ox, float oy, float oz, float dx, float dy, float dz,
-                                                  float t_min, float& best_t, uint32_t& best_prim,
-                                                  uint32_t& best_mk, Counts& cnt) {
+
+// ---------------------------------------------------------------------------------------------
+// The sweep with TWO rays per lane.  The arithmetic of the two rays is written on 2-vectors so
+// that it compiles to packed f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32
+// operations per lane per instruction), and the per-entry scalar fetch and branch are shared
+// by 128 rays.  Component k of every vector belongs to ray k; nothing mixes the two rays.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 dot3v(f32x2 ax, f32x2 ay, f32x2 az, f32x2 bx, f32x2 by, f32x2 bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+__device__ __forceinline__ f32x2 dot3s(float ax, float ay, float az, f32x2 bx, f32x2 by, f32x2 bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+
+struct Hit2 { float t[2]; uint32_t prim[2], mk[2]; };
+
+// 1 / x for both components.  v_rcp_f32 followed by two Newton steps with exact (fused)
+// residuals is bit-identical to the correctly rounded quotient for every f32 x with
+// 2^-23 <= |x| <= 8.5e37 -- checked exhaustively over all 2.5e9 such inputs on gfx950 by
+// tools/rcp_check.hip -- and costs 6 instructions for two rays instead of 22.  The caller takes
+// the full division when any lane is outside that range.
+constexpr float RCP_SHORT_MAX = 8.5e37f;
+__device__ __forceinline__ f32x2 rcp_short2(f32x2 x) {
+    f32x2 r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+    const f32x2 one = {1.0f, 1.0f};
+    f32x2 e = __builtin_elementwise_fma(-x, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    e = __builtin_elementwise_fma(-x, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    return r;
+}
+
+// SPHERES = false drops the sphere branch for scenes that have none.
+template <bool COUNT, bool SPHERES>
+__device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ ent_, uint32_t n_ent, bool valid0,
+                                                   bool valid1, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 dx, f32x2 dy,
+                                                   f32x2 dz, float t_min, float t_max, Hit2& h, Counts& cnt) {
     const const_f4_ptr ent = (const_f4_ptr)(uintptr_t)ent_;
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const bool nx = ix < 0.0f, ny = iy < 0.0f, nz = iz < 0.0f;   // math.rs:155: swap when inv_d < 0
+    const f32x2 one = {1.0f, 1.0f};
+    const f32x2 ix = one / dx, iy = one / dy, iz = one / dz;
+    const bool nx0 = ix.x < 0.0f, ny0 = iy.x < 0.0f, nz0 = iz.x < 0.0f;
+    const bool nx1 = ix.y < 0.0f, ny1 = iy.y < 0.0f, nz1 = iz.y < 0.0f;
     const float EPS = 1.1920929e-7f;
-    best_prim = RT_MISS;
-    best_mk = 0;
-    uint32_t cursor = valid ? 0u : n_ent;
+    float bt0 = t_max, bt1 = t_max;
+    uint32_t bp0 = RT_MISS, bp1 = RT_MISS, bm0 = 0, bm1 = 0;
+    uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
     for (uint32_t e = 0; e < n_ent; e++) {
-        const bool on = cursor == e;
-        if (__ballot(on) == 0ull) continue;
+        const bool on0 = cur0 == e, on1 = cur1 == e;
+        if (__ballot(on0 | on1) == 0ull) continue;
         const f32x4 a = ent[3 * e];
         const f32x4 b = ent[3 * e + 1];
         const uint32_t w = f2u(a.w);
         const uint32_t tag = w >> TAG_SHIFT;
         if (tag == TAG_BOX) {
-            if (COUNT) cnt.box += on ? 1u : 0u;
-            // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
-            // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
-            // per-axis early return equals the one test after the third axis because t_min only
-            // grows and t_max only shrinks.
-            const float x0 = (a.x - ox) * ix, x1 = (b.x - ox) * ix;
-            const float y0 = (a.y - oy) * iy, y1 = (b.y - oy) * iy;
-            const float z0 = (a.z - oz) * iz, z1 = (b.z - oz) * iz;
-            const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
-            const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), best_t);
-            const uint32_t nxt = tmx <= tmn ? (w & SKIP_MASK) : e + 1u;
-            cursor = on ? nxt : cursor;
+            if (COUNT) cnt.box += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
+            const f32x2 x0 = (a.x - ox) * ix, x1 = (b.x - ox) * ix;
+            const f32x2 y0 = (a.y - oy) * iy, y1 = (b.y - oy) * iy;
+            const f32x2 z0 = (a.z - oz) * iz, z1 = (b.z - oz) * iz;
+            const float tmn0 = fmaxf(fmaxf(fmaxf(nx0 ? x1.x : x0.x, ny0 ? y1.x : y0.x), nz0 ? z1.x : z0.x), t_min);
+            const float tmx0 = fminf(fminf(fminf(nx0 ? x0.x : x1.x, ny0 ? y0.x : y1.x), nz0 ? z0.x : z1.x), bt0);
+            const float tmn1 = fmaxf(fmaxf(fmaxf(nx1 ? x1.y : x0.y, ny1 ? y1.y : y0.y), nz1 ? z1.y : z0.y), t_min);
+            const float tmx1 = fminf(fminf(fminf(nx1 ? x0.y : x1.y, ny1 ? y0.y : y1.y), nz1 ? z0.y : z1.y), bt1);
+            const uint32_t skip = w & SKIP_MASK;
+            const uint32_t n0 = tmx0 <= tmn0 ? skip : e + 1u;
+            const uint32_t n1 = tmx1 <= tmn1 ? skip : e + 1u;
+            cur0 = on0 ? n0 : cur0;
+            cur1 = on1 ? n1 : cur1;
         } else if (tag == TAG_TRI) {
-            if (COUNT) cnt.tri += on ? 1u : 0u;
+            if (COUNT) cnt.tri += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
             const f32x4 c = ent[3 * e + 2];
-            const float px = dy * c.z - dz * c.y;
-            const float py = dz * c.x - dx * c.z;
-            const float pz = dx * c.y - dy * c.x;
-            const float det = dot3(b.x, b.y, b.z, px, py, pz);
-            const float inv_det = 1.0f / det;
-            const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-            const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
-            const float qx = ty * b.z - tz * b.y;
-            const float qy = tz * b.x - tx * b.z;
-            const float qz = tx * b.y - ty * b.x;
-            const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
-            const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-            // the reference's early returns (shape.rs:428-445) and acceptance test (shape.rs:297)
-            const bool hit = on & !(fabsf(det) < EPS) & !(u < 0.0f) & !(u > 1.0f) & !(v < 0.0f) &
-                             !(u + v > 1.0f) & (t >= t_min) & (t < best_t);
-            best_t = hit ? t : best_t;
-            best_prim = hit ? (f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u)) : best_prim;
-            best_mk = hit ? f2u(c.w) : best_mk;
-            cursor = on ? e + 1u : cursor;
-        } else {
-            if (COUNT) cnt.sph += on ? 1u : 0u;
-            const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
-            const float qa = dot3(dx, dy, dz, dx, dy, dz);
-            const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
-            const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
-            const float disc = half_b * half_b - qa * qc;
-            const float sqrtd = sqrtf(disc);
-            const float r0 = (-half_b - sqrtd) / qa;
-            const float r1 = (-half_b + sqrtd) / qa;
-            const bool bad0 = (r0 < t_min) | (best_t < r0);      // shape.rs:32-36, closed interval
-            const bool bad1 = (r1 < t_min) | (best_t < r1);
-            const float root = bad0 ? r1 : r0;
-            const bool hit = on & !(disc < 0.0f) & !(bad0 & bad1);
-            best_t = hit ? root : best_t;
-            best_prim = hit ? f2u(b.w) : best_prim;
-            best_mk = hit ? f2u(b.y) : best_mk;
-            cursor = on ? e + 1u : cursor;
+            const f32x2 px = dy * c.z - dz * c.y;
+            const f32x2 py = dz * c.x - dx * c.z;
+            const f32x2 pz = dx * c.y - dy * c.x;
+            const f32x2 det = dot3s(b.x, b.y, b.z, px, py, pz);
+            // lanes with |det| < eps never hit, so only huge / non-finite determinants need the
+            // full division (shape.rs:434: inv_det = 1.0 / det)
+            const bool wide = (on0 & !(fabsf(det.x) <= RCP_SHORT_MAX)) | (on1 & !(fabsf(det.y) <= RCP_SHORT_MAX));
+            f32x2 inv_det;
+            if (__ballot(wide) != 0ull) inv_det = one / det;
+            else inv_det = rcp_short2(det);
+            const f32x2 tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+            const f32x2 u = dot3v(tx, ty, tz, px, py, pz) * inv_det;
+            const f32x2 qx = ty * b.z - tz * b.y;
+            const f32x2 qy = tz * b.x - tx * b.z;
+            const f32x2 qz = tx * b.y - ty * b.x;
+            const f32x2 v = dot3v(dx, dy, dz, qx, qy, qz) * inv_det;
+            const f32x2 t = dot3s(c.x, c.y, c.z, qx, qy, qz) * inv_det;
+            const f32x2 uv = u + v;
+            const bool hit0 = on0 & !(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
+                              !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0);
+            const bool hit1 = on1 & !(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
+                              !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1);
+            const uint32_t id = f2u(b.w), mk = f2u(c.w);
+            bt0 = hit0 ? t.x : bt0;
+            bp0 = hit0 ? (id | (det.x < EPS ? PRIM_BACKFACE : 0u)) : bp0;
+            bm0 = hit0 ? mk : bm0;
+            bt1 = hit1 ? t.y : bt1;
+            bp1 = hit1 ? (id | (det.y < EPS ? PRIM_BACKFACE : 0u)) : bp1;
+            bm1 = hit1 ? mk : bm1;
+            cur0 = on0 ? e + 1u : cur0;
+            cur1 = on1 ? e + 1u : cur1;
+        } else if (SPHERES) {
+            if (COUNT) cnt.sph += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
+            const f32x2 ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
+            const f32x2 qa = dot3v(dx, dy, dz, dx, dy, dz);
+            const f32x2 half_b = dot3v(ocx, ocy, ocz, dx, dy, dz);
+            const f32x2 qc = dot3v(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
+            const f32x2 disc = half_b * half_b - qa * qc;
+            const f32x2 sqrtd = {sqrtf(disc.x), sqrtf(disc.y)};
+            const f32x2 r0 = (-half_b - sqrtd) / qa;
+            const f32x2 r1 = (-half_b + sqrtd) / qa;
+            const uint32_t id = f2u(b.w), mk = f2u(b.y);
+            {
+                const bool bad0 = (r0.x < t_min) | (bt0 < r0.x), bad1 = (r1.x < t_min) | (bt0 < r1.x);
+                const bool hit = on0 & !(disc.x < 0.0f) & !(bad0 & bad1);
+                bt0 = hit ? (bad0 ? r1.x : r0.x) : bt0;
+                bp0 = hit ? id : bp0;
+                bm0 = hit ? mk : bm0;
+            }
+            {
+                const bool bad0 = (r0.y < t_min) | (bt1 < r0.y), bad1 = (r1.y < t_min) | (bt1 < r1.y);
+                const bool hit = on1 & !(disc.y < 0.0f) & !(bad0 & bad1);
+                bt1 = hit ? (bad0 ? r1.y : r0.y) : bt1;
+                bp1 = hit ? id : bp1;
+                bm1 = hit ? mk : bm1;
+            }
+            cur0 = on0 ? e + 1u : cur0;
+            cur1 = on1 ? e + 1u : cur1;
         }
     }
+    h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1; h.mk[0] = bm0; h.mk[1] = bm1;
 }
 
 // ---------------------------------------------------------------------------------------------
 // rt_trace: AoS rays in, full hit records out (the hit-parity surface)
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT, bool SWEEP>
+__device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict__ out, size_t r, float ox, float oy,
+                                          float oz, float dx, float dy, float dz, float t, uint32_t prim, uint32_t mk) {
+    const float4* geo = (const float4*)sc.prim_geo;
+    rt_hit h;
+    if (prim == RT_MISS) {
+        h.t = 0.0f; h.prim_id = RT_MISS;
+        h.p[0] = h.p[1] = h.p[2] = 0.0f; h.n[0] = h.n[1] = h.n[2] = 0.0f;
+        h.front_face = 0; h.mat = 0;
+    } else {
+        const uint32_t id = prim & PRIM_ID_MASK;
+        const float4 g = geo[id];
+        const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
+        float nx, ny, nz;
+        if (sc.prim_meta[id] & META_SPHERE) {          // shape.rs:41
+            nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
+        } else {                                       // shape.rs:298-307
+            const bool bf = (prim & PRIM_BACKFACE) != 0;
+            nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
+        }
+        const bool front = dot3(dx, dy, dz, nx, ny, nz) < 0.0f;   // camera.rs:112-119
+        h.t = t; h.prim_id = id;
+        h.p[0] = px; h.p[1] = py; h.p[2] = pz;
+        h.n[0] = front ? nx : -nx; h.n[1] = front ? ny : -ny; h.n[2] = front ? nz : -nz;
+        h.front_face = front ? 1u : 0u;
+        h.mat = mk & MAT_MASK;
+    }
+    out[r] = h;
+}
+
+// SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene)
+template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
             rt_hit* __restrict__ out, Totals* totals) {
     const float4* ent = (const float4*)sc.entries;
-    const float4* geo = (const float4*)sc.prim_geo;
     Counts cnt{0, 0, 0};
-    // the trip count is the same for every lane of a wave (the sweep needs the wave converged)
-    for (size_t r0 = (size_t)blockIdx.x * RT_BLOCK; r0 < n; r0 += (size_t)gridDim.x * RT_BLOCK) {
-        const size_t r = r0 + threadIdx.x;
-        const bool valid = r < n;
-        float ox = 0, oy = 0, oz = 0, dx = 1, dy = 1, dz = 1;
-        if (valid) {
-            ox = rays[r * 6 + 0]; oy = rays[r * 6 + 1]; oz = rays[r * 6 + 2];
-            dx = rays[r * 6 + 3]; dy = rays[r * 6 + 4]; dz = rays[r * 6 + 5];
+    if (SWEEP) {
+        // the same two-rays-per-lane sweep the renderer uses; every wave takes 128 consecutive rays
+        const size_t wave = (size_t)blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
+        const size_t n_waves = (size_t)gridDim.x * (RT_BLOCK / 64);
+        const uint32_t lane = threadIdx.x & 63u;
+        for (size_t r0 = wave * 128; r0 < n; r0 += n_waves * 128) {
+            const size_t ra = r0 + lane, rb = ra + 64;
+            const bool va = ra < n, vb = rb < n;
+            float o0[3] = {0, 0, 0}, d0[3] = {1, 1, 1}, o1[3] = {0, 0, 0}, d1[3] = {1, 1, 1};
+            if (va) for (int k = 0; k < 3; k++) { o0[k] = rays[ra * 6 + k]; d0[k] = rays[ra * 6 + 3 + k]; }
+            if (vb) for (int k = 0; k < 3; k++) { o1[k] = rays[rb * 6 + k]; d1[k] = rays[rb * 6 + 3 + k]; }
+            Hit2 h;
+            closest_hit_sweep2<COUNT, SWEEP == 2>(ent, sc.n_entries, va, vb, f32x2{o0[0], o1[0]}, f32x2{o0[1], o1[1]},
+                                      f32x2{o0[2], o1[2]}, f32x2{d0[0], d1[0]}, f32x2{d0[1], d1[1]},
+                                      f32x2{d0[2], d1[2]}, t_min, t_max, h, cnt);
+            if (va) write_hit(sc, out, ra, o0[0], o0[1], o0[2], d0[0], d0[1], d0[2], h.t[0], h.prim[0], h.mk[0]);
+            if (vb) write_hit(sc, out, rb, o1[0], o1[1], o1[2], d1[0], d1[1], d1[2], h.t[1], h.prim[1], h.mk[1]);
         }
-        float t = t_max;
-        uint32_t prim = RT_MISS, mk = 0;
-        if (SWEEP) closest_hit_sweep<COUNT>(ent, sc.n_entries, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
-        else if (valid) closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
-        if (!valid) continue;
-        rt_hit h;
-        if (prim == RT_MISS) {
-            h.t = 0.0f; h.prim_id = RT_MISS;
-            h.p[0] = h.p[1] = h.p[2] = 0.0f; h.n[0] = h.n[1] = h.n[2] = 0.0f;
-            h.front_face = 0; h.mat = 0;
-        } else {
-            const uint32_t id = prim & PRIM_ID_MASK;
-            const float4 g = geo[id];
-            const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
-            float nx, ny, nz;
-            if (sc.prim_meta[id] & META_SPHERE) {          // shape.rs:41
-                nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
-            } else {                                       // shape.rs:298-307
-                const bool bf = (prim & PRIM_BACKFACE) != 0;
-                nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
-            }
-            const bool front = dot3(dx, dy, dz, nx, ny, nz) < 0.0f;   // camera.rs:112-119
-            h.t = t; h.prim_id = id;
-            h.p[0] = px; h.p[1] = py; h.p[2] = pz;
-            h.n[0] = front ? nx : -nx; h.n[1] = front ? ny : -ny; h.n[2] = front ? nz : -nz;
-            h.front_face = front ? 1u : 0u;
-            h.mat = mk & MAT_MASK;
+    } else {
+        for (size_t r = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (size_t)gridDim.x * RT_BLOCK) {
+            const float ox = rays[r * 6 + 0], oy = rays[r * 6 + 1], oz = rays[r * 6 + 2];
+            const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+            float t = t_max;
+            uint32_t prim, mk;
+            closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
+            write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim, mk);
         }
-        out[r] = h;
     }
     if (COUNT) {
         atomicAdd(&totals->box, (unsigned long long)cnt.box);
@@ -385,7 +462,42 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
 // ---------------------------------------------------------------------------------------------
 // trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
 // ---------------------------------------------------------------------------------------------
-template <bool COUNT, bool SWEEP>
+// what happens to a traced ray: terminate it (sky, emitter, depth cap -> its radiance goes to
+// Lbuf) or record the hit and report the material kind it must be queued under (7 = none)
+__device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, const float4* __restrict__ C,
+                                               uint2* __restrict__ hits, float4* __restrict__ Lbuf, uint32_t i,
+                                               uint32_t slot, float dx, float dy, float dz, float t, uint32_t prim,
+                                               uint32_t mk, uint32_t last_depth, float sky_intensity) {
+    if (prim == RT_MISS) {
+        // sky_color (main.rs:31-38): gradient on the y of the normalised direction
+        const float4 c = C[i];
+        const float len = sqrtf(dot3(dx, dy, dz, dx, dy, dz));
+        const float tt = 0.5f * (dy / len + 1.0f);
+        const float r = ((1.0f - tt) * 1.0f + tt * 0.5f) * sky_intensity;
+        const float gg = ((1.0f - tt) * 1.0f + tt * 0.7f) * sky_intensity;
+        const float bb = ((1.0f - tt) * 1.0f + tt * 1.0f) * sky_intensity;
+        Lbuf[slot] = make_float4(c.x * r, c.y * gg, c.z * bb, 0.0f);
+        return 7u;
+    }
+    const uint32_t k = mk >> KIND_SHIFT;
+    if (k == RT_MAT_EMISSIVE) {                            // emit, no scatter (material.rs:126-130)
+        const float4 c = C[i];
+        const float4 m = mats[2 * (mk & MAT_MASK)];
+        Lbuf[slot] = make_float4(c.x * m.x, c.y * m.y, c.z * m.z, 0.0f);
+        return 7u;
+    }
+    if (last_depth) {                                      // the next ray_color returns 0 (main.rs:41-43)
+        Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        return 7u;
+    }
+    hits[i] = make_uint2(f2u(t), prim);
+    return k;
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
+// ---------------------------------------------------------------------------------------------
+template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_WAVE)
 k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -398,43 +510,10 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
     if (seg >= g.n_seg) return;
     const uint32_t base = seg * g.seg_len;
     const uint32_t n = segcnt[seg];
+    const float t_max = __builtin_inff();                  // main.rs:46: t_max = f32::INFINITY
     uint32_t n0 = 0, n1 = 0, n2 = 0;
     Counts cnt{0, 0, 0};
-    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
-        const uint32_t i = base + j0 + lane;
-        const bool valid = j0 + lane < n;
-        uint32_t kind = 7u;                                // 7 = nothing to queue
-        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        if (valid) { a = A[i]; b = B[i]; }
-        float t = __builtin_inff();                        // main.rs:46: t_max = f32::INFINITY
-        uint32_t prim = RT_MISS, mk = 0;
-        if (SWEEP) closest_hit_sweep<COUNT>(ent, sc.n_entries, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
-        else if (valid) closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
-        if (valid) {
-            const uint32_t slot = f2u(a.w);
-            if (prim == RT_MISS) {
-                // sky_color (main.rs:31-38): gradient on the y of the normalised direction
-                const float4 c = C[i];
-                const float len = sqrtf(dot3(b.x, b.y, b.z, b.x, b.y, b.z));
-                const float tt = 0.5f * (b.y / len + 1.0f);
-                const float r = ((1.0f - tt) * 1.0f + tt * 0.5f) * sky_intensity;
-                const float gg = ((1.0f - tt) * 1.0f + tt * 0.7f) * sky_intensity;
-                const float bb = ((1.0f - tt) * 1.0f + tt * 1.0f) * sky_intensity;
-                Lbuf[slot] = make_float4(c.x * r, c.y * gg, c.z * bb, 0.0f);
-            } else {
-                const uint32_t k = mk >> KIND_SHIFT;
-                if (k == RT_MAT_EMISSIVE) {                // emit, no scatter (material.rs:126-130)
-                    const float4 c = C[i];
-                    const float4 m = mats[2 * (mk & MAT_MASK)];
-                    Lbuf[slot] = make_float4(c.x * m.x, c.y * m.y, c.z * m.z, 0.0f);
-                } else if (last_depth) {                   // the next ray_color returns 0 (main.rs:41-43)
-                    Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                } else {
-                    hits[i] = make_uint2(f2u(t), prim);
-                    kind = k;
-                }
-            }
-        }
+    auto enqueue = [&](uint32_t kind, uint32_t i) {
         uint32_t pos;
         pos = wave_append(kind == 0u, n0);
         if (kind == 0u) q0[base + pos] = i;
@@ -442,6 +521,43 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         if (kind == 1u) q1[base + pos] = i;
         pos = wave_append(kind == 2u, n2);
         if (kind == 2u) q2[base + pos] = i;
+    };
+    if (SWEEP) {
+        // two rays per lane: rays j0 + lane and j0 + 64 + lane
+        for (uint32_t j0 = 0; j0 < n; j0 += 128u) {
+            const uint32_t ia = base + j0 + lane, ib = ia + 64u;
+            const bool va = j0 + lane < n, vb = j0 + 64u + lane < n;
+            float4 a0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b0 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            float4 a1 = a0, b1 = b0;
+            if (va) { a0 = A[ia]; b0 = B[ia]; }
+            if (vb) { a1 = A[ib]; b1 = B[ib]; }
+            Hit2 h;
+            closest_hit_sweep2<COUNT, SWEEP == 2>(ent, sc.n_entries, va, vb, f32x2{a0.x, a1.x}, f32x2{a0.y, a1.y},
+                                      f32x2{a0.z, a1.z}, f32x2{b0.x, b1.x}, f32x2{b0.y, b1.y}, f32x2{b0.z, b1.z},
+                                      t_min, t_max, h, cnt);
+            uint32_t ka = 7u, kb = 7u;
+            if (va) ka = finish_ray(mats, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0], h.prim[0], h.mk[0],
+                                    last_depth, sky_intensity);
+            if (vb) kb = finish_ray(mats, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1], h.prim[1], h.mk[1],
+                                    last_depth, sky_intensity);
+            enqueue(ka, ia);
+            enqueue(kb, ib);
+        }
+    } else {
+        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+            const uint32_t i = base + j0 + lane;
+            const bool valid = j0 + lane < n;
+            uint32_t kind = 7u;
+            if (valid) {
+                const float4 a = A[i], b = B[i];
+                float t = t_max;
+                uint32_t prim, mk;
+                closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
+                kind = finish_ray(mats, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, mk, last_depth,
+                                  sky_intensity);
+            }
+            enqueue(kind, i);
+        }
     }
     if (lane == 0) {
         qcnt[seg] = n0;
@@ -644,8 +760,10 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
 #define RT_TRACE_API(CNT, SWP)                                                                          \
     hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n, \
                        t_min, t_max, (rt_hit*)d_hits, d_counts)
-    if (sc.sweep) { if (count) RT_TRACE_API(true, true); else RT_TRACE_API(false, true); }
-    else { if (count) RT_TRACE_API(true, false); else RT_TRACE_API(false, false); }
+    const int mode = sc.sweep ? (sc.has_spheres ? 2 : 1) : 0;
+    if (mode == 2) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
+    else if (mode == 1) { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
+    else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
 #undef RT_TRACE_API
     return check_launch();
 }
@@ -667,8 +785,10 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
                        rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
                        last_depth ? 1u : 0u, t_min, sky_intensity)
-    if (sc.sweep) { if (count) RT_TRACE(true, true); else RT_TRACE(false, true); }
-    else { if (count) RT_TRACE(true, false); else RT_TRACE(false, false); }
+    const int mode = sc.sweep ? (sc.has_spheres ? 2 : 1) : 0;
+    if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
+    else if (mode == 1) { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
+    else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
 #undef RT_TRACE
     return check_launch();
 }

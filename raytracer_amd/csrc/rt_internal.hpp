@@ -42,6 +42,7 @@ struct FlatScene {
     std::vector<uint32_t> prim_meta;   // material index | META_SPHERE
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
+    bool has_spheres = false;
     size_t n_entries() const { return entries.size() / 12; }
     size_t n_prims() const { return prim_meta.size(); }
 };
@@ -71,6 +72,7 @@ struct DevScene {
     uint32_t n_mats;
     uint32_t kinds_present;
     uint32_t sweep;           // 1: wave-synchronous sweep of the entry array, 0: per-lane walk
+    uint32_t has_spheres;     // the scene holds at least one sphere
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default
