@@ -711,16 +711,9 @@ k_accumulate(BatchGeom g, const float4* __restrict__ Lbuf, float* __restrict__ a
 __global__ void __launch_bounds__(RT_BLOCK)
 k_count_rays(const uint32_t* __restrict__ segcnt, uint32_t n, Totals* totals) {
     unsigned long long s = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += RT_BLOCK) s += segcnt[i];
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) s += segcnt[i];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-    __shared__ unsigned long long part[RT_BLOCK / 64];
-    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int k = 0; k < RT_BLOCK / 64; k++) t += part[k];
-        totals->rays += t;
-    }
+    if ((threadIdx.x & 63u) == 0 && s != 0) atomicAdd(&totals->rays, s);   // integer: order-independent
 }
 
 // main.rs:369-373 + rgb_to_u32 (math.rs:112-116)
@@ -809,8 +802,8 @@ int launch_accumulate(const LaunchCfg& cfg, const BatchGeom& g, const RenderBuff
     hipStream_t st = (hipStream_t)cfg.stream;
     hipLaunchKernelGGL(k_accumulate, dim3(grid_for(g.n_pix_slots, cfg.grid_cap)), dim3(RT_BLOCK), 0, st, g,
                        (const float4*)rb.Lbuf, (float*)d_accum);
-    hipLaunchKernelGGL(k_count_rays, dim3(1), dim3(RT_BLOCK), 0, st, (const uint32_t*)rb.segcnt,
-                       max_bounces * g.n_seg, rb.totals);
+    hipLaunchKernelGGL(k_count_rays, dim3(grid_for((size_t)max_bounces * g.n_seg, 256)), dim3(RT_BLOCK), 0, st,
+                       (const uint32_t*)rb.segcnt, max_bounces * g.n_seg, rb.totals);
     return check_launch();
 }
 

@@ -123,3 +123,47 @@ def test_tonemap_matches_oracle(rt, ob, ctx):
     want = ob.tonemap(acc, 16)
     got = ctx.tonemap(acc, 16)
     assert np.array_equal(got, want)
+
+
+def test_world_render_entry_point(rt, ob, ctx):
+    """rt_world_render (the render() drop-in of the host layer) equals the same render issued
+    through the core ABI on a mirrored scene."""
+    w = rt.World.world2(ctx, variant=1)
+    img, st = w.render(80, 64, 6, 6)
+    cam = w.camera(80, 64)
+    img2, st2 = w.scene.render(cam, w.params(80, 64, 6, 6))
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
+    assert st["rays_traced"] == st2["rays_traced"] and st["paths"] == 80 * 64 * 6
+    osc = ob.Scene.world2(asset("thing.obj"), 1)
+    sc = mirror(rt, ctx, osc)
+    img3, _ = sc.render(product_camera(rt, osc, 80, 64), rt.Scene.params(80, 64, 6, 6, osc.sky))
+    assert np.array_equal(img.view(np.uint32), img3.view(np.uint32))
+    w.close()
+
+
+def test_soup_scene_hits_match_oracle(rt, ob, ctx):
+    """The synthetic triangle soup + sphere field (the bandwidth stress scene) at a small size:
+    host generator -> GPU scene, same description -> oracle; hits must agree."""
+    from helpers import assert_hits_equal, random_rays
+    w = rt.World.soup(ctx, 20000, grid=8, seed=12345)
+    osc = ob.Scene.from_description(w.materials(), w.objects(), w.root_kind)
+    assert w.scene.num_prims == 20000 + 64 + 1
+    rays = random_rays(ob, 9, 200000, -100.0, 100.0)
+    rays["o"][:, 2] = np.abs(rays["o"][:, 2])
+    want, _ = osc.trace(rays)
+    assert (want["prim_id"] != ob.MISS).sum() > 1000
+    assert_hits_equal(w.scene.trace(rays), want)
+    w.close()
+
+
+def test_short_reciprocal_is_exact_on_this_gpu():
+    """tools/rcp_check compares the triangle test's short reciprocal with the correctly rounded
+    1/x over every f32 bit pattern; it exits non-zero on any in-range mismatch."""
+    import os
+    import subprocess
+    from helpers import ROOT
+    exe = os.path.join(ROOT, "tools", "rcp_check")
+    assert os.path.exists(exe), "build() compiles tools/rcp_check"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mismatches in range 0" in out.stdout
