@@ -55,20 +55,36 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// One wavefront pipeline: a stream and the state of the batch in flight on it.  A render keeps
+// two batches in flight (one per pipeline) so that the latency-bound stages of one batch
+// (shade, raygen, accumulate) run under the issue-bound closest-hit kernel of the other.
+struct Pipe {
+    hipStream_t stream = nullptr;
+    DeviceBuffer rayA[2], rayB[2], rayC[2], hits, queue[3], lbuf, segcnt, qcnt;
+    size_t capacity = 0;
+    std::vector<hipEvent_t> events;     // profiling pool
+    hipEvent_t accum_done = nullptr;    // this pipe's last accumulate
+};
+
 struct rt_context {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // = pipes[0].stream: the stream callers may order work on
     uint32_t grid_cap = 2048;
-    // wavefront state, grown on demand and kept between calls
-    DeviceBuffer rayA[2], rayB[2], rayC[2], hits, queue[3], lbuf, segcnt, qcnt, totals, scratch_in, scratch_out;
+    Pipe pipes[2];
+    DeviceBuffer totals, scratch_in, scratch_out;
     uint32_t wave_target = 8192;
-    size_t capacity = 0;
-    std::vector<hipEvent_t> events;
+    int n_pipes = 2;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
-    LaunchCfg cfg() const { return LaunchCfg{(void*)stream, grid_cap, wave_target}; }
+    LaunchCfg cfg(int pipe = 0) const { return LaunchCfg{(void*)pipes[pipe].stream, grid_cap, wave_target}; }
     ~rt_context() {
-        for (hipEvent_t e : events) (void)hipEventDestroy(e);
-        if (stream) (void)hipStreamDestroy(stream);
+        for (Pipe& p : pipes) {
+            for (hipEvent_t e : p.events) (void)hipEventDestroy(e);
+            if (p.accum_done) (void)hipEventDestroy(p.accum_done);
+            if (p.stream) (void)hipStreamDestroy(p.stream);
+        }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -91,26 +107,28 @@ int set_device(rt_context* ctx) {
     return RT_OK;
 }
 
-int ensure_capacity(rt_context* ctx, size_t paths) {
-    if (paths <= ctx->capacity) return RT_OK;
-    for (int k = 0; k < 2; k++) {
-        HIP_TRY(ctx->rayA[k].ensure(paths * 16));
-        HIP_TRY(ctx->rayB[k].ensure(paths * 16));
-        HIP_TRY(ctx->rayC[k].ensure(paths * 16));
-    }
-    HIP_TRY(ctx->hits.ensure(paths * 8));
-    for (int k = 0; k < 3; k++) HIP_TRY(ctx->queue[k].ensure(paths * 4));
-    HIP_TRY(ctx->lbuf.ensure(paths * 16));
+int ensure_capacity(rt_context* ctx, Pipe& pp, size_t paths, size_t n_seg) {
     HIP_TRY(ctx->totals.ensure(sizeof(Totals)));
-    ctx->capacity = paths;
+    HIP_TRY(pp.segcnt.ensure((size_t)(MAX_DEPTH + 1) * n_seg * sizeof(uint32_t)));
+    HIP_TRY(pp.qcnt.ensure((size_t)3 * n_seg * sizeof(uint32_t)));
+    if (paths <= pp.capacity) return RT_OK;
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(pp.rayA[k].ensure(paths * 16));
+        HIP_TRY(pp.rayB[k].ensure(paths * 16));
+        HIP_TRY(pp.rayC[k].ensure(paths * 16));
+    }
+    HIP_TRY(pp.hits.ensure(paths * 8));
+    for (int k = 0; k < 3; k++) HIP_TRY(pp.queue[k].ensure(paths * 4));
+    HIP_TRY(pp.lbuf.ensure(paths * 16));
+    pp.capacity = paths;
     return RT_OK;
 }
 
-int get_events(rt_context* ctx, size_t n) {
-    while (ctx->events.size() < n) {
+int get_events(Pipe& pp, size_t n) {
+    while (pp.events.size() < n) {
         hipEvent_t e;
         HIP_TRY(hipEventCreate(&e));
-        ctx->events.push_back(e);
+        pp.events.push_back(e);
     }
     return RT_OK;
 }
@@ -144,7 +162,14 @@ int rt_context_create(int device_id, rt_context** out) {
         const long v = std::atol(e);
         if (v > 0) ctx->wave_target = (uint32_t)v;
     }
-    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (Pipe& pp : ctx->pipes) {
+        HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&pp.accum_done, hipEventDisableTiming));
+    }
+    ctx->stream = ctx->pipes[0].stream;
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::atoi(e) == 1 ? 1 : 2;
     *out = ctx.release();
     return RT_OK;
 }
@@ -356,59 +381,73 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     const uint32_t n_samples = p->sample_end - p->sample_begin;
     size_t max_paths = p->max_paths_in_flight ? p->max_paths_in_flight : DEFAULT_MAX_PATHS;
     if (max_paths < 64) max_paths = 64;
-    // batch = (a run of whole tiles) x (a run of samples)
-    const size_t tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
-    const uint32_t samples_per_batch =
+    // batch = (a run of whole tiles) x (a run of samples); with more than one batch, two are kept
+    // in flight, so each gets half of the path budget
+    size_t tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
+    uint32_t samples_per_batch =
         (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
-    rc = ensure_capacity(ctx, tiles_per_batch * 64 * samples_per_batch);
-    if (rc) return rc;
-
-    RenderBuffers rb;
-    rb.hits = ctx->hits.p;
-    for (int k = 0; k < 3; k++) rb.queue[k] = (uint32_t*)ctx->queue[k].p;
-    rb.Lbuf = ctx->lbuf.p;
-    rb.totals = (Totals*)ctx->totals.p;
-    rb.capacity = ctx->capacity;
-    const LaunchCfg cfg = ctx->cfg();
-    hipStream_t st = ctx->stream;
-
-    size_t ev_used = 0;
-    struct Span { size_t e0, e1; int what; };
-    std::vector<Span> spans;
-    double ms_by_kind[2] = {0.0, 0.0};
-    auto fold_spans = [&]() -> int {           // needs the stream to be idle
-        for (const Span& sp : spans) {
-            float m = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&m, ctx->events[sp.e0], ctx->events[sp.e1]));
-            ms_by_kind[sp.what] += m;
+    size_t n_batches = ((n_tiles + tiles_per_batch - 1) / tiles_per_batch) *
+                       ((n_samples + samples_per_batch - 1) / samples_per_batch);
+    const int n_pipes = (n_batches > 1 && ctx->n_pipes > 1) ? 2 : 1;
+    if (n_pipes == 2) {
+        max_paths = std::max<size_t>(64, max_paths / 2);
+        tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
+        samples_per_batch =
+            (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
+    }
+    const uint32_t wave_target = ctx->wave_target;
+    auto segments = [&](BatchGeom& g) {        // one wave per segment, a multiple of 64 slots long
+        g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + wave_target - 1) / wave_target + 63u) / 64u * 64u);
+        g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
+    };
+    {
+        BatchGeom g0;
+        g0.n_slots = (uint32_t)(tiles_per_batch * 64 * samples_per_batch);
+        segments(g0);
+        for (int k = 0; k < n_pipes; k++) {
+            rc = ensure_capacity(ctx, ctx->pipes[k], g0.n_slots, g0.n_seg);
+            if (rc) return rc;
         }
-        spans.clear();
-        ev_used = 0;
+    }
+
+    hipStream_t st0 = ctx->pipes[0].stream;
+    struct Span { size_t e0, e1; int what; };
+    std::vector<Span> spans[2];
+    size_t ev_used[2] = {0, 0};
+    double ms_by_kind[2] = {0.0, 0.0};
+    auto fold_spans = [&]() -> int {           // needs both streams to be idle
+        for (int k = 0; k < 2; k++) {
+            for (const Span& sp : spans[k]) {
+                float m = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&m, ctx->pipes[k].events[sp.e0], ctx->pipes[k].events[sp.e1]));
+                ms_by_kind[sp.what] += m;
+            }
+            spans[k].clear();
+            ev_used[k] = 0;
+        }
         return RT_OK;
     };
-    auto mark = [&](int what, auto&& launch) -> int {
-        if (!profile) return launch();
-        int r = get_events(ctx, ev_used + 2);
-        if (r) return r;
-        if (hipEventRecord(ctx->events[ev_used], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
-        int lr = launch();
-        if (hipEventRecord(ctx->events[ev_used + 1], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
-        spans.push_back(Span{ev_used, ev_used + 1, what});
-        ev_used += 2;
-        return lr;
-    };
 
-    HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), st));
+    HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), st0));
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     HIP_TRY(hipEventCreate(&ev_begin));
     HIP_TRY(hipEventCreate(&ev_end));
-    HIP_TRY(hipEventRecord(ev_begin, st));
+    HIP_TRY(hipEventRecord(ev_begin, st0));
+    if (n_pipes == 2) {                        // the second stream starts after whatever precedes the call
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st0));
+        HIP_TRY(hipStreamWaitEvent(ctx->pipes[1].stream, ctx->ev_fork, 0));
+    }
 
     uint64_t trace_launches = 0;
-    int cur = 0;
+    size_t batch = 0;
+    int last_pipe = -1;
     for (size_t tile0 = 0; tile0 < n_tiles; tile0 += tiles_per_batch) {
         const size_t nt = std::min(tiles_per_batch, n_tiles - tile0);
-        for (uint32_t s0 = 0; s0 < n_samples; s0 += samples_per_batch) {
+        for (uint32_t s0 = 0; s0 < n_samples; s0 += samples_per_batch, batch++) {
+            const int k = (int)(batch % (size_t)n_pipes);
+            Pipe& pp = ctx->pipes[k];
+            hipStream_t st = pp.stream;
+            const LaunchCfg cfg = ctx->cfg(k);
             BatchGeom g;
             g.width = p->width; g.height = p->height;
             g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
@@ -418,16 +457,31 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.sample_base = p->sample_begin + s0;
             g.n_samples = std::min(samples_per_batch, n_samples - s0);
             g.n_slots = g.n_pix_slots * g.n_samples;
-            // segments: one per wave, a multiple of 64 slots long
-            g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + cfg.wave_target - 1) / cfg.wave_target + 63u) / 64u * 64u);
-            g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
-            HIP_TRY(ctx->segcnt.ensure((size_t)(MAX_DEPTH + 1) * g.n_seg * sizeof(uint32_t)));
-            HIP_TRY(ctx->qcnt.ensure((size_t)3 * g.n_seg * sizeof(uint32_t)));
-            rb.segcnt = (uint32_t*)ctx->segcnt.p;
-            rb.qcnt = (uint32_t*)ctx->qcnt.p;
+            segments(g);
+
+            RenderBuffers rb;
+            rb.hits = pp.hits.p;
+            for (int q = 0; q < 3; q++) rb.queue[q] = (uint32_t*)pp.queue[q].p;
+            rb.Lbuf = pp.lbuf.p;
+            rb.totals = (Totals*)ctx->totals.p;
+            rb.capacity = pp.capacity;
+            rb.segcnt = (uint32_t*)pp.segcnt.p;
+            rb.qcnt = (uint32_t*)pp.qcnt.p;
+            int cur = 0;
             auto bind = [&]() {
-                rb.cur = RayBuffers{ctx->rayA[cur].p, ctx->rayB[cur].p, ctx->rayC[cur].p};
-                rb.next = RayBuffers{ctx->rayA[cur ^ 1].p, ctx->rayB[cur ^ 1].p, ctx->rayC[cur ^ 1].p};
+                rb.cur = RayBuffers{pp.rayA[cur].p, pp.rayB[cur].p, pp.rayC[cur].p};
+                rb.next = RayBuffers{pp.rayA[cur ^ 1].p, pp.rayB[cur ^ 1].p, pp.rayC[cur ^ 1].p};
+            };
+            auto mark = [&](int what, auto&& launch) -> int {
+                if (!profile) return launch();
+                int r = get_events(pp, ev_used[k] + 2);
+                if (r) return r;
+                if (hipEventRecord(pp.events[ev_used[k]], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
+                int lr = launch();
+                if (hipEventRecord(pp.events[ev_used[k] + 1], st) != hipSuccess) return fail(RT_ERR_DEVICE, "hipEventRecord");
+                spans[k].push_back(Span{ev_used[k], ev_used[k] + 1, what});
+                ev_used[k] += 2;
+                return lr;
             };
             bind();
             if (launch_raygen(cfg, *cam, g, p->seed, rb)) return fail(RT_ERR_DEVICE, "raygen launch failed");
@@ -444,23 +498,32 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 cur ^= 1;
                 bind();
             }
+            // batches add to the same pixels: accumulate in batch order, across the two streams
+            if (last_pipe >= 0 && last_pipe != k)
+                HIP_TRY(hipStreamWaitEvent(st, ctx->pipes[last_pipe].accum_done, 0));
             if (launch_accumulate(cfg, g, rb, d_accum, p->max_bounces))
                 return fail(RT_ERR_DEVICE, "accumulate launch failed");
-            if (profile && ev_used > 4096) {
-                // keep the event pool bounded on long renders: fold what has finished so far
-                HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipEventRecord(pp.accum_done, st));
+            last_pipe = k;
+            if (profile && ev_used[k] > 4096) {
+                // keep the event pools bounded on long renders: fold what has finished so far
+                for (int q = 0; q < n_pipes; q++) HIP_TRY(hipStreamSynchronize(ctx->pipes[q].stream));
                 rc = fold_spans();
                 if (rc) return rc;
             }
         }
     }
-    HIP_TRY(hipEventRecord(ev_end, st));
+    if (n_pipes == 2) {                        // join: everything is complete when stream 0 is
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->pipes[1].stream));
+        HIP_TRY(hipStreamWaitEvent(st0, ctx->ev_join, 0));
+    }
+    HIP_TRY(hipEventRecord(ev_end, st0));
 
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
         Totals t;
-        HIP_TRY(hipMemcpyAsync(&t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(&t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, st0));
+        HIP_TRY(hipStreamSynchronize(st0));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->ms_render = ms;
