@@ -192,13 +192,22 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
     float bt0 = t_max, bt1 = t_max;
     uint32_t bp0 = RT_MISS, bp1 = RT_MISS, bm0 = 0, bm1 = 0;
     uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
-    for (uint32_t e = 0; e < n_ent; e++) {
+    for (uint32_t e = 0;; e++) {
+        // next entry that some lane stands on: a scalar scan that leaves the vector state alone
+        while (e < n_ent && __ballot((cur0 == e) | (cur1 == e)) == 0ull) e++;
+        if (e >= n_ent) break;
         const bool on0 = cur0 == e, on1 = cur1 == e;
-        if (__ballot(on0 | on1) == 0ull) continue;
         const f32x4 a = ent[3 * e];
         const f32x4 b = ent[3 * e + 1];
         const uint32_t w = f2u(a.w);
         const uint32_t tag = w >> TAG_SHIFT;
+        // What this entry does to a lane that is `on`.  The traversal state itself is written in
+        // ONE place, after the branches: updated there in place it stays in the same registers
+        // around the loop (written inside the branches it gets renamed and copied back).
+        uint32_t nxt0 = e + 1u, nxt1 = e + 1u;
+        bool hit0 = false, hit1 = false;
+        float nt0 = 0.0f, nt1 = 0.0f;
+        uint32_t np0 = 0, np1 = 0, nmk = 0;
         if (tag == TAG_BOX) {
             if (COUNT) cnt.box += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
             const f32x2 x0 = (a.x - ox) * ix, x1 = (b.x - ox) * ix;
@@ -209,10 +218,8 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
             const float tmn1 = fmaxf(fmaxf(fmaxf(nx1 ? x1.y : x0.y, ny1 ? y1.y : y0.y), nz1 ? z1.y : z0.y), t_min);
             const float tmx1 = fminf(fminf(fminf(nx1 ? x0.y : x1.y, ny1 ? y0.y : y1.y), nz1 ? z0.y : z1.y), bt1);
             const uint32_t skip = w & SKIP_MASK;
-            const uint32_t n0 = tmx0 <= tmn0 ? skip : e + 1u;
-            const uint32_t n1 = tmx1 <= tmn1 ? skip : e + 1u;
-            cur0 = on0 ? n0 : cur0;
-            cur1 = on1 ? n1 : cur1;
+            nxt0 = tmx0 <= tmn0 ? skip : e + 1u;
+            nxt1 = tmx1 <= tmn1 ? skip : e + 1u;
         } else if (tag == TAG_TRI) {
             if (COUNT) cnt.tri += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
             const f32x4 c = ent[3 * e + 2];
@@ -234,19 +241,15 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
             const f32x2 v = dot3v(dx, dy, dz, qx, qy, qz) * inv_det;
             const f32x2 t = dot3s(c.x, c.y, c.z, qx, qy, qz) * inv_det;
             const f32x2 uv = u + v;
-            const bool hit0 = on0 & !(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
-                              !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0);
-            const bool hit1 = on1 & !(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
-                              !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1);
-            const uint32_t id = f2u(b.w), mk = f2u(c.w);
-            bt0 = hit0 ? t.x : bt0;
-            bp0 = hit0 ? (id | (det.x < EPS ? PRIM_BACKFACE : 0u)) : bp0;
-            bm0 = hit0 ? mk : bm0;
-            bt1 = hit1 ? t.y : bt1;
-            bp1 = hit1 ? (id | (det.y < EPS ? PRIM_BACKFACE : 0u)) : bp1;
-            bm1 = hit1 ? mk : bm1;
-            cur0 = on0 ? e + 1u : cur0;
-            cur1 = on1 ? e + 1u : cur1;
+            hit0 = on0 & !(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
+                   !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0);
+            hit1 = on1 & !(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
+                   !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1);
+            const uint32_t id = f2u(b.w);
+            nmk = f2u(c.w);
+            nt0 = t.x; nt1 = t.y;
+            np0 = id | (det.x < EPS ? PRIM_BACKFACE : 0u);
+            np1 = id | (det.y < EPS ? PRIM_BACKFACE : 0u);
         } else if (SPHERES) {
             if (COUNT) cnt.sph += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
             const f32x2 ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
@@ -257,24 +260,27 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
             const f32x2 sqrtd = {sqrtf(disc.x), sqrtf(disc.y)};
             const f32x2 r0 = (-half_b - sqrtd) / qa;
             const f32x2 r1 = (-half_b + sqrtd) / qa;
-            const uint32_t id = f2u(b.w), mk = f2u(b.y);
+            np0 = np1 = f2u(b.w);
+            nmk = f2u(b.y);
             {
                 const bool bad0 = (r0.x < t_min) | (bt0 < r0.x), bad1 = (r1.x < t_min) | (bt0 < r1.x);
-                const bool hit = on0 & !(disc.x < 0.0f) & !(bad0 & bad1);
-                bt0 = hit ? (bad0 ? r1.x : r0.x) : bt0;
-                bp0 = hit ? id : bp0;
-                bm0 = hit ? mk : bm0;
+                hit0 = on0 & !(disc.x < 0.0f) & !(bad0 & bad1);
+                nt0 = bad0 ? r1.x : r0.x;
             }
             {
                 const bool bad0 = (r0.y < t_min) | (bt1 < r0.y), bad1 = (r1.y < t_min) | (bt1 < r1.y);
-                const bool hit = on1 & !(disc.y < 0.0f) & !(bad0 & bad1);
-                bt1 = hit ? (bad0 ? r1.y : r0.y) : bt1;
-                bp1 = hit ? id : bp1;
-                bm1 = hit ? mk : bm1;
+                hit1 = on1 & !(disc.y < 0.0f) & !(bad0 & bad1);
+                nt1 = bad0 ? r1.y : r0.y;
             }
-            cur0 = on0 ? e + 1u : cur0;
-            cur1 = on1 ? e + 1u : cur1;
         }
+        cur0 = on0 ? nxt0 : cur0;
+        cur1 = on1 ? nxt1 : cur1;
+        bt0 = hit0 ? nt0 : bt0;
+        bt1 = hit1 ? nt1 : bt1;
+        bp0 = hit0 ? np0 : bp0;
+        bp1 = hit1 ? np1 : bp1;
+        bm0 = hit0 ? nmk : bm0;
+        bm1 = hit1 ? nmk : bm1;
     }
     h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1; h.mk[0] = bm0; h.mk[1] = bm1;
 }
