@@ -102,20 +102,28 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell_plane_1024_1k", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debugging)")
+    ap.add_argument("--size", default="", help="override WxH (debugging)")
+    ap.add_argument("--emulate", default="", help="r/N: render rank r's share of an N-rank job on this one GPU (debugging)")
+    ap.add_argument("--backend", default=os.environ.get("RT_DIST_BACKEND", ""),
+                    help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep"], default="auto")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env()
+    rank, world, local = D.init_from_env(args.backend or None)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if local >= torch.cuda.device_count():      # several ranks on one GPU (tests only)
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     kind, width, height, spp, depth = WORKLOADS[args.workload]
     if args.spp:
         spp = args.spp
+    if args.size:
+        width, height = (int(v) for v in args.size.lower().split("x"))
 
     ctx = rt.Context(local)
     t0 = time.time()
@@ -124,17 +132,15 @@ def main():
     wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
                              "sweep": rt.TRAVERSAL_SWEEP}[args.traversal])
     cam = wld.camera(width, height)
-    rects, samples = partition(width, height, spp, world, rank)
+    bands, samples = partition(width, height, spp, world, rank)
+    if args.emulate:
+        er, en = (int(v) for v in args.emulate.split("/"))
+        bands, samples = partition(width, height, spp, en, er)
     accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
 
-    def render(flags, smp, want_stats=True):
-        tot = None
-        for rect in rects:
-            p = wld.params(width, height, spp, depth, rect=rect, samples=smp, flags=flags, max_paths=args.max_paths)
-            st = wld.scene.render_device(cam, p, accum.data_ptr(), want_stats=want_stats)
-            if st is not None:
-                tot = st if tot is None else {k: tot[k] + st[k] for k in st}
-        return tot
+    def render(flags, smp):
+        p = wld.params(width, height, spp, depth, samples=smp, flags=flags, max_paths=args.max_paths, bands=bands)
+        return wld.scene.render_device(cam, p, accum.data_ptr())
 
     def step(flags):
         accum.zero_()
@@ -197,14 +203,16 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
-                       "partition": f"{len(rects)} row-band rect(s) x samples [{samples[0]},{samples[1]}) per rank",
+                       "partition": f"rank 0: {bands[0]}-row bands b with b % {bands[1]} == {bands[2]}, "
+                                    f"samples [{samples[0]},{samples[1]})",
                        "rays_per_step": int(total_rays / args.steps), "paths_per_step": width * height * spp,
-                       "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3)},
+                       "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3),
+                       "accum_sum": float(accum.double().sum().item())},
             "roofline": {
                 "bound": "hbm", "kernel": "k_trace (closest hit)",
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": measured_traffic() if args.workload == "cornell_plane_1024_1k" and not args.spp else None,
+                "traffic": measured_traffic() if args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size) else None,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": int(bytes_per_ray * rays / max(launches, 1)),
                 "note": "frac > 1: the tree (3.4 KB on this workload) is served from the scalar cache, the kernel is "

@@ -90,6 +90,12 @@ typedef struct {
     uint64_t seed;                     /* key of the counter-based RNG */
     uint32_t flags;                    /* RT_RENDER_* */
     uint32_t max_paths_in_flight;      /* 0 = library default */
+    /* Interleaved row bands inside the rectangle, for splitting a frame by image tile over
+     * several GPUs with even load: with band_count > 1 only the bands b (of band_rows rows each,
+     * counted from y0) with b % band_count == band_index are rendered.  band_rows must be a
+     * multiple of 8; band_count 0 or 1 renders the whole rectangle. */
+    uint32_t band_rows, band_count, band_index;
+    uint32_t reserved;
 } rt_render_params;
 #define RT_RENDER_PROFILE 1u       /* time every closest-hit launch with HIP events */
 #define RT_RENDER_COUNT_VISITS 2u  /* count box / triangle / sphere tests (slower) */

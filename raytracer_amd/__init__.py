@@ -46,7 +46,9 @@ class RenderParams(C.Structure):
                 ("x0", C.c_uint32), ("y0", C.c_uint32), ("x1", C.c_uint32), ("y1", C.c_uint32),
                 ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32),
                 ("max_bounces", C.c_uint32), ("t_min", C.c_float), ("sky_intensity", C.c_float),
-                ("seed", C.c_uint64), ("flags", C.c_uint32), ("max_paths_in_flight", C.c_uint32)]
+                ("seed", C.c_uint64), ("flags", C.c_uint32), ("max_paths_in_flight", C.c_uint32),
+                ("band_rows", C.c_uint32), ("band_count", C.c_uint32), ("band_index", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -257,11 +259,13 @@ class Scene:
 
     @staticmethod
     def params(width, height, spp, max_bounces, sky, rect=None, samples=None, seed=DEFAULT_SEED,
-               flags=0, t_min=0.001, max_paths=0):
+               flags=0, t_min=0.001, max_paths=0, bands=None):
+        """bands = (band_rows, band_count, band_index) renders only that interleaved band group."""
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, width, height)
         s0, s1 = samples if samples is not None else (0, spp)
+        br, bc, bi = bands if bands is not None else (0, 0, 0)
         return RenderParams(width, height, x0, y0, x1, y1, s0, s1, max_bounces, t_min, sky, seed,
-                            flags, max_paths)
+                            flags, max_paths, br, bc, bi, 0)
 
     def render(self, camera, params, accum=None):
         """Host-buffer render; returns (accum[H,W,3] sums, stats dict)."""

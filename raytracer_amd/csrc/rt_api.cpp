@@ -376,7 +376,26 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     const bool profile = (p->flags & RT_RENDER_PROFILE) != 0;
     const bool count = (p->flags & RT_RENDER_COUNT_VISITS) != 0;
     const uint32_t rw = p->x1 - p->x0, rh = p->y1 - p->y0;
-    const uint32_t tiles_x = (rw + 7) / 8, tiles_y = (rh + 7) / 8;
+    const uint32_t tiles_x = (rw + 7) / 8, tiles_y_all = (rh + 7) / 8;
+    const uint32_t band_count = p->band_count > 1 ? p->band_count : 1;
+    uint32_t band_tile_rows = 1, tiles_y = tiles_y_all;
+    uint64_t n_pixels = (uint64_t)rw * rh;
+    if (band_count > 1) {
+        if (p->band_rows == 0 || p->band_rows % 8 != 0) return fail(RT_ERR_INVALID, "band_rows must be a positive multiple of 8");
+        if (p->band_index >= band_count) return fail(RT_ERR_INVALID, "band_index out of range");
+        band_tile_rows = p->band_rows / 8;
+        tiles_y = 0;
+        n_pixels = 0;
+        for (uint32_t ty = 0; ty < tiles_y_all; ty++)
+            if ((ty / band_tile_rows) % band_count == p->band_index) {
+                tiles_y++;
+                n_pixels += (uint64_t)rw * std::min(8u, rh - ty * 8u);
+            }
+        if (tiles_y == 0) {                    // this band group owns nothing of the rectangle
+            if (stats) std::memset(stats, 0, sizeof(*stats));
+            return RT_OK;
+        }
+    }
     const size_t n_tiles = (size_t)tiles_x * tiles_y;
     const uint32_t n_samples = p->sample_end - p->sample_begin;
     size_t max_paths = p->max_paths_in_flight ? p->max_paths_in_flight : DEFAULT_MAX_PATHS;
@@ -457,6 +476,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.sample_base = p->sample_begin + s0;
             g.n_samples = std::min(samples_per_batch, n_samples - s0);
             g.n_slots = g.n_pix_slots * g.n_samples;
+            g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
             segments(g);
 
             RenderBuffers rb;
@@ -528,7 +548,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         HIP_TRY(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->ms_render = ms;
         stats->rays_traced = t.rays;
-        stats->paths = (uint64_t)rw * rh * n_samples;
+        stats->paths = n_pixels * n_samples;
         stats->box_tests = t.box; stats->tri_tests = t.tri; stats->sph_tests = t.sph;
         stats->trace_launches = trace_launches;
         rc = fold_spans();

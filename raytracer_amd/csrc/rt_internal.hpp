@@ -103,6 +103,8 @@ struct BatchGeom {
     uint32_t sample_base, n_samples;
     uint32_t n_slots;             // n_pix_slots * n_samples
     uint32_t n_seg, seg_len;
+    // interleaved row bands: the batch's tile rows are the owned ones, in order (band_count 1: all)
+    uint32_t band_tile_rows, band_count, band_index;
 };
 
 struct RayBuffers {

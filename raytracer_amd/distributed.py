@@ -34,12 +34,11 @@ def reduce_to_root(accum):
     return accum
 
 
-def render_partitioned(render_rect, width, height, spp, rank, world_size, accum):
-    """Runs `render_rect(rect, (s0, s1), accum)` for every rectangle of this rank's partition, then
-    reduces.  `render_rect` adds the linear sample sums of that rectangle/sample range into
-    `accum` (the GPU path passes a closure over Scene.render_device).  Returns accum (complete
-    on rank 0 only)."""
-    rects, samples = partition(width, height, spp, world_size, rank)
-    for rect in rects:
-        render_rect(rect, samples, accum)
+def render_partitioned(render_part, width, height, spp, rank, world_size, accum):
+    """Runs `render_part(bands, (s0, s1), accum)` for this rank's partition, then reduces.
+    `render_part` adds the linear sample sums of that band group / sample range into `accum`
+    (the GPU path passes a closure over Scene.render_device).  Returns accum (complete on rank 0
+    only)."""
+    bands, samples = partition(width, height, spp, world_size, rank)
+    render_part(bands, samples, accum)
     return reduce_to_root(accum)

@@ -38,13 +38,12 @@ def band_rects(width, height, groups, group):
 
 
 def partition(width, height, spp, world_size, rank):
-    """-> (list of rects, (sample_begin, sample_end)) for `rank`."""
+    """-> (bands, (sample_begin, sample_end)) for `rank`, where bands = (band_rows, band_count,
+    band_index) is the interleaved band group of the full frame this rank renders (the renderer
+    takes it in one call, rt_render_params.band_*); band_rects() lists the same pixels as
+    rectangles."""
     if not 0 <= rank < world_size:
         raise ValueError("rank out of range")
-    bands, parts = split_factors(world_size, spp)
-    group, part = rank % bands, rank // bands
-    if bands == 1:
-        rects = [(0, 0, width, height)]
-    else:
-        rects = band_rects(width, height, bands, group)
-    return rects, sample_range(spp, parts, part)
+    groups, parts = split_factors(world_size, spp)
+    group, part = rank % groups, rank // groups
+    return (BAND_ROWS, groups, group), sample_range(spp, parts, part)

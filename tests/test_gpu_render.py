@@ -79,6 +79,21 @@ def test_deterministic_and_partition_invariant(rt, ob, ctx):
     for rng_ in [(0, 5), (5, 12)]:
         acc, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, samples=rng_), accum=acc)
     np.testing.assert_allclose(acc, full, rtol=2e-5, atol=1e-6)
+    # interleaved row bands (how ranks split a frame by tile): two band groups tile the frame
+    acc = np.zeros_like(full)
+    rays = 0
+    for idx in (0, 1):
+        acc, s = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, bands=(16, 2, idx)), accum=acc)
+        rays += s["rays_traced"]
+        assert s["paths"] == sum(min(16, h - y0) for y0 in range(16 * idx, h, 32)) * w * spp
+    np.testing.assert_allclose(acc, full, rtol=2e-5, atol=1e-6)
+    assert rays == st["rays_traced"]
+    only0, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, bands=(16, 2, 0)))
+    assert (only0[16:32] == 0).all() and (only0[0:16].sum() > 0) and (only0[32:48].sum() > 0)
+    with pytest.raises(rt.RtError):
+        sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, bands=(12, 2, 0)))
+    with pytest.raises(rt.RtError):
+        sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, bands=(16, 2, 2)))
     # small batches (many wavefront batches) give the same image as one big batch
     small, _ = sc.render(cam, rt.Scene.params(w, h, spp, depth, osc.sky, max_paths=64 * 40))
     np.testing.assert_allclose(small, full, rtol=2e-5, atol=1e-6)

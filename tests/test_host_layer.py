@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(rt):
     assert rt.material_dt.itemsize == 24 and rt.sphere_dt.itemsize == 20
     assert rt.triangle_dt.itemsize == 52 and rt.ray_dt.itemsize == 24
     assert rt.hit_dt.itemsize == 40 and rt.camera_dt.itemsize == 76
-    assert ctypes.sizeof(rt.RenderParams) == 64 and ctypes.sizeof(rt.Stats) == 72
+    assert ctypes.sizeof(rt.RenderParams) == 80 and ctypes.sizeof(rt.Stats) == 72
 
 
 def test_no_gpu_fails_loudly(rt):

@@ -17,9 +17,9 @@ def test_partition_covers_every_pixel_sample_once(world, shape):
     w, h, spp = shape
     cover = np.zeros((h, w), dtype=np.int64)
     for r in range(world):
-        rects, (s0, s1) = P.partition(w, h, spp, world, r)
-        assert 0 <= s0 <= s1 <= spp
-        for x0, y0, x1, y1 in rects:
+        (rows, groups, group), (s0, s1) = P.partition(w, h, spp, world, r)
+        assert 0 <= s0 <= s1 <= spp and rows % 8 == 0 and group < groups
+        for x0, y0, x1, y1 in P.band_rects(w, h, groups, group):
             assert 0 <= x0 < x1 <= w and 0 <= y0 < y1 <= h
             assert y0 % 8 == 0                      # cuts keep the 8x8 tiles whole
             cover[y0:y1, x0:x1] += s1 - s0
@@ -39,15 +39,16 @@ def test_split_factors():
 
 def _fake_render(width, height):
     """Stands in for the GPU call: a deterministic value per (pixel, sample, channel)."""
-    def render_rect(rect, samples, accum):
-        x0, y0, x1, y1 = rect
-        ys, xs = np.mgrid[y0:y1, x0:x1]
+    def render_part(bands, samples, accum):
+        rows, groups, group = bands
         img = accum.view(height, width, 3)
-        for s in range(*samples):
-            v = ((xs * 73 + ys * 151 + s * 31) % 97).astype(np.float32) / 7.0
-            for c in range(3):
-                img[y0:y1, x0:x1, c] += torch.from_numpy(v * (c + 1))
-    return render_rect
+        for x0, y0, x1, y1 in P.band_rects(width, height, groups, group):
+            ys, xs = np.mgrid[y0:y1, x0:x1]
+            for s in range(*samples):
+                v = ((xs * 73 + ys * 151 + s * 31) % 97).astype(np.float32) / 7.0
+                for c in range(3):
+                    img[y0:y1, x0:x1, c] += torch.from_numpy(v * (c + 1))
+    return render_part
 
 
 def _worker(rank, world, port, w, h, spp, out_path):
@@ -82,5 +83,5 @@ def test_partitioned_render_and_reduce_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), w, h, spp, out), nprocs=world, join=True)
     got = np.load(out)
     want = torch.zeros(h * w * 3, dtype=torch.float32)
-    _fake_render(w, h)((0, 0, w, h), (0, spp), want)
+    _fake_render(w, h)((P.BAND_ROWS, 1, 0), (0, spp), want)
     np.testing.assert_allclose(got, want.numpy(), rtol=1e-6)
