@@ -34,6 +34,7 @@ WORKLOADS = {
     "world1_1080p_256": ("world1", 1920, 1080, 256, 6),
     "thing_glass_2048_512": ("world2_glass", 2048, 2048, 512, 6),
     "cornell_full_512_64": ("cornell", 512, 512, 64, 8),
+    "soup_10m_4k_256": ("soup", 3840, 2160, 256, 16),
 }
 
 
@@ -46,6 +47,8 @@ def make_world(ctx, kind):
         return rt.World.world1(ctx)
     if kind == "world2_glass":
         return rt.World.world2(ctx, variant=1)
+    if kind == "soup":
+        return rt.World.soup(ctx, int(os.environ.get("RT_SOUP_TRIS", "10000000")), grid=64, seed=12345)
     raise ValueError(kind)
 
 

@@ -144,7 +144,7 @@ int rt_scene_set_traversal(rt_scene* scene, int mode);
 int rt_scene_commit(rt_scene* scene);
 size_t rt_scene_num_prims(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
-/* host-only scenes: copies the flattened pre-order entry array (12 floats per entry) */
+/* host-only scenes: copies the flattened pre-order entry array (16 floats per entry) */
 int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
 
 /* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */

@@ -242,7 +242,7 @@ class Scene:
 
     def entries(self):
         n = self.num_entries
-        out = np.zeros((n, 12), dtype=np.float32)
+        out = np.zeros((n, 16), dtype=np.float32)
         _check(lib.rt_scene_get_entries(self.h, _ptr(out), out.size))
         return out
 

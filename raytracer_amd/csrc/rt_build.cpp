@@ -54,10 +54,10 @@ struct Builder {
 
     size_t push_entry() {
         size_t i = out.n_entries();
-        out.entries.resize(out.entries.size() + 12, 0.0f);
+        out.entries.resize(out.entries.size() + ENTRY_FLOATS, 0.0f);
         return i;
     }
-    float* entry(size_t i) { return &out.entries[i * 12]; }
+    float* entry(size_t i) { return &out.entries[i * ENTRY_FLOATS]; }
 
     size_t push_box(const Box& b) {
         size_t i = push_entry();
@@ -75,7 +75,6 @@ struct Builder {
         e[0] = o.sphere.c[0]; e[1] = o.sphere.c[1]; e[2] = o.sphere.c[2];
         e[3] = u2f(TAG_SPH << TAG_SHIFT);
         e[4] = o.sphere.r;
-        e[5] = u2f(matkind(o.sphere.mat));
         e[7] = u2f(o.prim_base);
     }
     void push_triangle(uint32_t local) {
@@ -88,7 +87,6 @@ struct Builder {
         }
         e[3] = u2f(TAG_TRI << TAG_SHIFT);
         e[7] = u2f(mesh->prim_base + local);
-        e[11] = u2f(matkind(t.mat));
     }
 
     // compute_aabb (shape.rs:218-233): tight box of the triangles, then +-0.0001 on every face
@@ -139,7 +137,7 @@ struct Builder {
         }
         std::vector<uint32_t> idx(n);
         std::iota(idx.begin(), idx.end(), 0u);
-        out.entries.reserve(out.entries.size() + (2 * n + 1) * 12);
+        out.entries.reserve(out.entries.size() + (2 * n + 1) * ENTRY_FLOATS);
         emit_mesh_range(idx.data(), n, 0);     // Mesh::hit enters at the root node (shape.rs:455)
         mesh = nullptr;
     }
@@ -211,7 +209,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
             if (o.sphere.mat >= mats.size()) return "sphere material index out of range";
             float* g = &out.prim_geo[(size_t)o.prim_base * 4];
             g[0] = o.sphere.c[0]; g[1] = o.sphere.c[1]; g[2] = o.sphere.c[2]; g[3] = o.sphere.r;
-            out.prim_meta[o.prim_base] = o.sphere.mat | META_SPHERE;
+            out.prim_meta[o.prim_base] = b.matkind(o.sphere.mat) | META_SPHERE;
             out.has_spheres = true;
             out.kinds_present |= 1u << mats[o.sphere.mat].kind;
             Box bx;                            // Sphere::get_aabb, shape.rs:47-52
@@ -227,7 +225,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
                 float len = std::sqrt((t.n0[0] * t.n0[0] + t.n0[1] * t.n0[1]) + t.n0[2] * t.n0[2]);
                 float* g = &out.prim_geo[((size_t)o.prim_base + i) * 4];
                 g[0] = t.n0[0] / len; g[1] = t.n0[1] / len; g[2] = t.n0[2] / len; g[3] = 0.0f;
-                out.prim_meta[o.prim_base + i] = t.mat;
+                out.prim_meta[o.prim_base + i] = b.matkind(t.mat);
                 out.kinds_present |= 1u << mats[t.mat].kind;
             }
             b.obj_box[oi] = bx;

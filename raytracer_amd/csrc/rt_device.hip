@@ -44,17 +44,15 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
-                                            float t_min, float& best_t, uint32_t& best_prim,
-                                            uint32_t& best_mk, Counts& cnt) {
+                                            float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     // math.rs:152: inv_d = 1.0 / ray_dir[axis]; the same value at every box, so hoisted
     const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
     const float EPS = 1.1920929e-7f;           // f32::EPSILON
     best_prim = RT_MISS;
-    best_mk = 0;
     uint32_t i = 0;
     while (i < n_ent) {
-        const float4 a = ent[3 * i];
-        const float4 b = ent[3 * i + 1];
+        const float4 a = ent[4 * i];
+        const float4 b = ent[4 * i + 1];
         const uint32_t w = f2u(a.w);
         const uint32_t tag = w >> TAG_SHIFT;
         if (tag == TAG_BOX) {
@@ -79,7 +77,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
             i = miss ? (w & SKIP_MASK) : i + 1;
         } else if (tag == TAG_TRI) {
             if (COUNT) cnt.tri++;
-            const float4 c = ent[3 * i + 2];
+            const float4 c = ent[4 * i + 2];
             // a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2
             const float px = dy * c.z - dz * c.y;          // pvec = dir x v0v2
             const float py = dz * c.x - dx * c.z;
@@ -99,7 +97,6 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                         if (t >= t_min && t < best_t) {    // shape.rs:297
                             best_t = t;
                             best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
-                            best_mk = f2u(c.w);
                         }
                     }
                 }
@@ -124,7 +121,6 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                 if (ok) {
                     best_t = root;
                     best_prim = f2u(b.w);
-                    best_mk = f2u(b.y);
                 }
             }
             i = i + 1;
@@ -141,15 +137,14 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
 // bit-identical; lanes whose cursor is elsewhere idle for that entry.  Must be called with the
 // whole wave converged; lanes without a ray pass valid = false.
 // ---------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const f32x4 __attribute__((address_space(4)))* const_f4_ptr;
-
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const f32x16 __attribute__((address_space(4)))* const_entry_ptr;
 
 // ---------------------------------------------------------------------------------------------
-// The sweep with TWO rays per lane.  The arithmetic of the two rays is written on 2-vectors so
-// that it compiles to packed f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32
-// operations per lane per instruction), and the per-entry scalar fetch and branch are shared
-// by 128 rays.  Component k of every vector belongs to ray k; nothing mixes the two rays.
+// The sweep carries TWO rays per lane.  Their arithmetic is written on 2-vectors so that it
+// compiles to packed f32 instructions (v_pk_mul_f32 / v_pk_add_f32: two IEEE f32 operations
+// per lane per instruction) and the per-entry scalar fetch and branch are shared by 128 rays.
+// Component k of every vector belongs to ray k; nothing mixes the two rays.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -160,7 +155,7 @@ __device__ __forceinline__ f32x2 dot3s(float ax, float ay, float az, f32x2 bx, f
     return (ax * bx + ay * by) + az * bz;
 }
 
-struct Hit2 { float t[2]; uint32_t prim[2], mk[2]; };
+struct Hit2 { float t[2]; uint32_t prim[2]; };
 
 // 1 / x for both components.  v_rcp_f32 followed by two Newton steps with exact (fused)
 // residuals is bit-identical to the correctly rounded quotient for every f32 x with
@@ -178,41 +173,56 @@ __device__ __forceinline__ f32x2 rcp_short2(f32x2 x) {
     return r;
 }
 
+// dst = (lane in mask) ? src : dst.  One instruction with a tied operand and the lane mask
+// taken straight from scalar registers: the sweep's state is updated in place, in one block
+// after the branches, and so stays in the same registers around the loop (left to the register
+// allocator it gets renamed by every update and copied back, 16 moves per entry).
+__device__ __forceinline__ void select_into(float& dst, float src, unsigned long long mask) {
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask));
+}
+__device__ __forceinline__ void select_into(uint32_t& dst, uint32_t src, unsigned long long mask) {
+    asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask));
+}
+
 // SPHERES = false drops the sphere branch for scenes that have none.
 template <bool COUNT, bool SPHERES>
 __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ ent_, uint32_t n_ent, bool valid0,
                                                    bool valid1, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 dx, f32x2 dy,
                                                    f32x2 dz, float t_min, float t_max, Hit2& h, Counts& cnt) {
-    const const_f4_ptr ent = (const_f4_ptr)(uintptr_t)ent_;
+    const const_entry_ptr ent = (const_entry_ptr)(uintptr_t)ent_;
     const f32x2 one = {1.0f, 1.0f};
     const f32x2 ix = one / dx, iy = one / dy, iz = one / dz;
-    const bool nx0 = ix.x < 0.0f, ny0 = iy.x < 0.0f, nz0 = iz.x < 0.0f;
+    const bool nx0 = ix.x < 0.0f, ny0 = iy.x < 0.0f, nz0 = iz.x < 0.0f;   // math.rs:155: swap when inv_d < 0
     const bool nx1 = ix.y < 0.0f, ny1 = iy.y < 0.0f, nz1 = iz.y < 0.0f;
     const float EPS = 1.1920929e-7f;
     float bt0 = t_max, bt1 = t_max;
-    uint32_t bp0 = RT_MISS, bp1 = RT_MISS, bm0 = 0, bm1 = 0;
+    uint32_t bp0 = RT_MISS, bp1 = RT_MISS;
     uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
     for (uint32_t e = 0;; e++) {
-        // next entry that some lane stands on: a scalar scan that leaves the vector state alone
-        while (e < n_ent && __ballot((cur0 == e) | (cur1 == e)) == 0ull) e++;
+        // next entry that some lane stands on: a scalar scan that leaves the vector state alone;
+        // on0 / on1 = lanes whose ray 0 / ray 1 is at entry e
+        unsigned long long on0, on1;
+        for (;;) {
+            on0 = __ballot(cur0 == e);
+            on1 = __ballot(cur1 == e);
+            if ((on0 | on1) != 0ull || e >= n_ent) break;
+            e++;
+        }
         if (e >= n_ent) break;
-        const bool on0 = cur0 == e, on1 = cur1 == e;
-        const f32x4 a = ent[3 * e];
-        const f32x4 b = ent[3 * e + 1];
-        const uint32_t w = f2u(a.w);
+        const f32x16 E = ent[e];                       // one s_load_dwordx16
+        const uint32_t w = f2u(E[3]);
         const uint32_t tag = w >> TAG_SHIFT;
-        // What this entry does to a lane that is `on`.  The traversal state itself is written in
-        // ONE place, after the branches: updated there in place it stays in the same registers
-        // around the loop (written inside the branches it gets renamed and copied back).
+        // What the entry does to a lane that is on it; the state is written after the branches.
         uint32_t nxt0 = e + 1u, nxt1 = e + 1u;
-        bool hit0 = false, hit1 = false;
-        float nt0 = 0.0f, nt1 = 0.0f;
-        uint32_t np0 = 0, np1 = 0, nmk = 0;
         if (tag == TAG_BOX) {
-            if (COUNT) cnt.box += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
-            const f32x2 x0 = (a.x - ox) * ix, x1 = (b.x - ox) * ix;
-            const f32x2 y0 = (a.y - oy) * iy, y1 = (b.y - oy) * iy;
-            const f32x2 z0 = (a.z - oz) * iz, z1 = (b.z - oz) * iz;
+            if (COUNT) cnt.box += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
+            // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
+            // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
+            // per-axis early return equals the one test after the third axis because t_min only
+            // grows and t_max only shrinks.
+            const f32x2 x0 = (E[0] - ox) * ix, x1 = (E[4] - ox) * ix;
+            const f32x2 y0 = (E[1] - oy) * iy, y1 = (E[5] - oy) * iy;
+            const f32x2 z0 = (E[2] - oz) * iz, z1 = (E[6] - oz) * iz;
             const float tmn0 = fmaxf(fmaxf(fmaxf(nx0 ? x1.x : x0.x, ny0 ? y1.x : y0.x), nz0 ? z1.x : z0.x), t_min);
             const float tmx0 = fminf(fminf(fminf(nx0 ? x0.x : x1.x, ny0 ? y0.x : y1.x), nz0 ? z0.x : z1.x), bt0);
             const float tmn1 = fmaxf(fmaxf(fmaxf(nx1 ? x1.y : x0.y, ny1 ? y1.y : y0.y), nz1 ? z1.y : z0.y), t_min);
@@ -220,76 +230,74 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
             const uint32_t skip = w & SKIP_MASK;
             nxt0 = tmx0 <= tmn0 ? skip : e + 1u;
             nxt1 = tmx1 <= tmn1 ? skip : e + 1u;
-        } else if (tag == TAG_TRI) {
-            if (COUNT) cnt.tri += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
-            const f32x4 c = ent[3 * e + 2];
-            const f32x2 px = dy * c.z - dz * c.y;
-            const f32x2 py = dz * c.x - dx * c.z;
-            const f32x2 pz = dx * c.y - dy * c.x;
-            const f32x2 det = dot3s(b.x, b.y, b.z, px, py, pz);
-            // lanes with |det| < eps never hit, so only huge / non-finite determinants need the
-            // full division (shape.rs:434: inv_det = 1.0 / det)
-            const bool wide = (on0 & !(fabsf(det.x) <= RCP_SHORT_MAX)) | (on1 & !(fabsf(det.y) <= RCP_SHORT_MAX));
-            f32x2 inv_det;
-            if (__ballot(wide) != 0ull) inv_det = one / det;
-            else inv_det = rcp_short2(det);
-            const f32x2 tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-            const f32x2 u = dot3v(tx, ty, tz, px, py, pz) * inv_det;
-            const f32x2 qx = ty * b.z - tz * b.y;
-            const f32x2 qy = tz * b.x - tx * b.z;
-            const f32x2 qz = tx * b.y - ty * b.x;
-            const f32x2 v = dot3v(dx, dy, dz, qx, qy, qz) * inv_det;
-            const f32x2 t = dot3s(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-            const f32x2 uv = u + v;
-            hit0 = on0 & !(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
-                   !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0);
-            hit1 = on1 & !(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
-                   !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1);
-            const uint32_t id = f2u(b.w);
-            nmk = f2u(c.w);
-            nt0 = t.x; nt1 = t.y;
-            np0 = id | (det.x < EPS ? PRIM_BACKFACE : 0u);
-            np1 = id | (det.y < EPS ? PRIM_BACKFACE : 0u);
-        } else if (SPHERES) {
-            if (COUNT) cnt.sph += (on0 ? 1u : 0u) + (on1 ? 1u : 0u);
-            const f32x2 ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
-            const f32x2 qa = dot3v(dx, dy, dz, dx, dy, dz);
-            const f32x2 half_b = dot3v(ocx, ocy, ocz, dx, dy, dz);
-            const f32x2 qc = dot3v(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
-            const f32x2 disc = half_b * half_b - qa * qc;
-            const f32x2 sqrtd = {sqrtf(disc.x), sqrtf(disc.y)};
-            const f32x2 r0 = (-half_b - sqrtd) / qa;
-            const f32x2 r1 = (-half_b + sqrtd) / qa;
-            np0 = np1 = f2u(b.w);
-            nmk = f2u(b.y);
-            {
-                const bool bad0 = (r0.x < t_min) | (bt0 < r0.x), bad1 = (r1.x < t_min) | (bt0 < r1.x);
-                hit0 = on0 & !(disc.x < 0.0f) & !(bad0 & bad1);
-                nt0 = bad0 ? r1.x : r0.x;
+        } else {
+            unsigned long long hit0, hit1;
+            float nt0, nt1;
+            uint32_t np0, np1;
+            if (!SPHERES || tag == TAG_TRI) {
+                if (COUNT) cnt.tri += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
+                // E[0..2] = v0, E[4..6] = v0v1, E[8..10] = v0v2
+                const f32x2 px = dy * E[10] - dz * E[9];
+                const f32x2 py = dz * E[8] - dx * E[10];
+                const f32x2 pz = dx * E[9] - dy * E[8];
+                const f32x2 det = dot3s(E[4], E[5], E[6], px, py, pz);
+                // lanes with |det| < eps never hit, so only huge / non-finite determinants need
+                // the full division (shape.rs:434: inv_det = 1.0 / det)
+                const unsigned long long wide = (on0 & __ballot(!(fabsf(det.x) <= RCP_SHORT_MAX))) |
+                                                (on1 & __ballot(!(fabsf(det.y) <= RCP_SHORT_MAX)));
+                f32x2 inv_det;
+                if (wide != 0ull) inv_det = one / det;
+                else inv_det = rcp_short2(det);
+                const f32x2 tx = ox - E[0], ty = oy - E[1], tz = oz - E[2];
+                const f32x2 u = dot3v(tx, ty, tz, px, py, pz) * inv_det;
+                const f32x2 qx = ty * E[6] - tz * E[5];
+                const f32x2 qy = tz * E[4] - tx * E[6];
+                const f32x2 qz = tx * E[5] - ty * E[4];
+                const f32x2 v = dot3v(dx, dy, dz, qx, qy, qz) * inv_det;
+                const f32x2 t = dot3s(E[8], E[9], E[10], qx, qy, qz) * inv_det;
+                const f32x2 uv = u + v;
+                // the reference's early returns (shape.rs:428-445) and acceptance test (shape.rs:297)
+                hit0 = on0 & __ballot(!(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
+                                      !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0));
+                hit1 = on1 & __ballot(!(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
+                                      !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1));
+                const uint32_t id = f2u(E[7]);
+                nt0 = t.x; nt1 = t.y;
+                np0 = id | (det.x < EPS ? PRIM_BACKFACE : 0u);
+                np1 = id | (det.y < EPS ? PRIM_BACKFACE : 0u);
+            } else {
+                if (COUNT) cnt.sph += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
+                // E[0..2] = centre, E[4] = radius
+                const f32x2 ocx = ox - E[0], ocy = oy - E[1], ocz = oz - E[2];
+                const f32x2 qa = dot3v(dx, dy, dz, dx, dy, dz);
+                const f32x2 half_b = dot3v(ocx, ocy, ocz, dx, dy, dz);
+                const f32x2 qc = dot3v(ocx, ocy, ocz, ocx, ocy, ocz) - E[4] * E[4];
+                const f32x2 disc = half_b * half_b - qa * qc;
+                const f32x2 sqrtd = {sqrtf(disc.x), sqrtf(disc.y)};
+                const f32x2 r0 = (-half_b - sqrtd) / qa;
+                const f32x2 r1 = (-half_b + sqrtd) / qa;
+                np0 = np1 = f2u(E[7]);
+                // shape.rs:32-36, closed interval
+                const bool b00 = (r0.x < t_min) | (bt0 < r0.x), b01 = (r1.x < t_min) | (bt0 < r1.x);
+                const bool b10 = (r0.y < t_min) | (bt1 < r0.y), b11 = (r1.y < t_min) | (bt1 < r1.y);
+                hit0 = on0 & __ballot(!(disc.x < 0.0f) & !(b00 & b01));
+                hit1 = on1 & __ballot(!(disc.y < 0.0f) & !(b10 & b11));
+                nt0 = b00 ? r1.x : r0.x;
+                nt1 = b10 ? r1.y : r0.y;
             }
-            {
-                const bool bad0 = (r0.y < t_min) | (bt1 < r0.y), bad1 = (r1.y < t_min) | (bt1 < r1.y);
-                hit1 = on1 & !(disc.y < 0.0f) & !(bad0 & bad1);
-                nt1 = bad0 ? r1.y : r0.y;
-            }
+            select_into(bt0, nt0, hit0);
+            select_into(bt1, nt1, hit1);
+            select_into(bp0, np0, hit0);
+            select_into(bp1, np1, hit1);
         }
-        cur0 = on0 ? nxt0 : cur0;
-        cur1 = on1 ? nxt1 : cur1;
-        bt0 = hit0 ? nt0 : bt0;
-        bt1 = hit1 ? nt1 : bt1;
-        bp0 = hit0 ? np0 : bp0;
-        bp1 = hit1 ? np1 : bp1;
-        bm0 = hit0 ? nmk : bm0;
-        bm1 = hit1 ? nmk : bm1;
+        select_into(cur0, nxt0, on0);
+        select_into(cur1, nxt1, on1);
     }
-    h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1; h.mk[0] = bm0; h.mk[1] = bm1;
+    h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1;
 }
 
-// ---------------------------------------------------------------------------------------------
-// rt_trace: AoS rays in, full hit records out (the hit-parity surface)
-// ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict__ out, size_t r, float ox, float oy,
-                                          float oz, float dx, float dy, float dz, float t, uint32_t prim, uint32_t mk) {
+                                          float oz, float dx, float dy, float dz, float t, uint32_t prim) {
     const float4* geo = (const float4*)sc.prim_geo;
     rt_hit h;
     if (prim == RT_MISS) {
@@ -299,9 +307,10 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
     } else {
         const uint32_t id = prim & PRIM_ID_MASK;
         const float4 g = geo[id];
+        const uint32_t meta = sc.prim_meta[id];
         const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
         float nx, ny, nz;
-        if (sc.prim_meta[id] & META_SPHERE) {          // shape.rs:41
+        if (meta & META_SPHERE) {                      // shape.rs:41
             nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
         } else {                                       // shape.rs:298-307
             const bool bf = (prim & PRIM_BACKFACE) != 0;
@@ -312,7 +321,7 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
         h.p[0] = px; h.p[1] = py; h.p[2] = pz;
         h.n[0] = front ? nx : -nx; h.n[1] = front ? ny : -ny; h.n[2] = front ? nz : -nz;
         h.front_face = front ? 1u : 0u;
-        h.mat = mk & MAT_MASK;
+        h.mat = meta & MAT_MASK;
     }
     out[r] = h;
 }
@@ -339,17 +348,17 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             closest_hit_sweep2<COUNT, SWEEP == 2>(ent, sc.n_entries, va, vb, f32x2{o0[0], o1[0]}, f32x2{o0[1], o1[1]},
                                       f32x2{o0[2], o1[2]}, f32x2{d0[0], d1[0]}, f32x2{d0[1], d1[1]},
                                       f32x2{d0[2], d1[2]}, t_min, t_max, h, cnt);
-            if (va) write_hit(sc, out, ra, o0[0], o0[1], o0[2], d0[0], d0[1], d0[2], h.t[0], h.prim[0], h.mk[0]);
-            if (vb) write_hit(sc, out, rb, o1[0], o1[1], o1[2], d1[0], d1[1], d1[2], h.t[1], h.prim[1], h.mk[1]);
+            if (va) write_hit(sc, out, ra, o0[0], o0[1], o0[2], d0[0], d0[1], d0[2], h.t[0], h.prim[0]);
+            if (vb) write_hit(sc, out, rb, o1[0], o1[1], o1[2], d1[0], d1[1], d1[2], h.t[1], h.prim[1]);
         }
     } else {
         for (size_t r = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (size_t)gridDim.x * RT_BLOCK) {
             const float ox = rays[r * 6 + 0], oy = rays[r * 6 + 1], oz = rays[r * 6 + 2];
             const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
             float t = t_max;
-            uint32_t prim, mk;
-            closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, mk, cnt);
-            write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim, mk);
+            uint32_t prim;
+            closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
     if (COUNT) {
@@ -473,10 +482,11 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
 // ---------------------------------------------------------------------------------------------
 // what happens to a traced ray: terminate it (sky, emitter, depth cap -> its radiance goes to
 // Lbuf) or record the hit and report the material kind it must be queued under (7 = none)
-__device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, const float4* __restrict__ C,
-                                               uint2* __restrict__ hits, float4* __restrict__ Lbuf, uint32_t i,
-                                               uint32_t slot, float dx, float dy, float dz, float t, uint32_t prim,
-                                               uint32_t mk, uint32_t last_depth, float sky_intensity) {
+__device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
+                                               const float4* __restrict__ C, uint2* __restrict__ hits,
+                                               float4* __restrict__ Lbuf, uint32_t i, uint32_t slot, float dx,
+                                               float dy, float dz, float t, uint32_t prim, uint32_t last_depth,
+                                               float sky_intensity) {
     if (prim == RT_MISS) {
         // sky_color (main.rs:31-38): gradient on the y of the normalised direction
         const float4 c = C[i];
@@ -488,7 +498,8 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
         Lbuf[slot] = make_float4(c.x * r, c.y * gg, c.z * bb, 0.0f);
         return 7u;
     }
-    const uint32_t k = mk >> KIND_SHIFT;
+    const uint32_t mk = prim_meta[prim & PRIM_ID_MASK];
+    const uint32_t k = (mk >> KIND_SHIFT) & 3u;
     if (k == RT_MAT_EMISSIVE) {                            // emit, no scatter (material.rs:126-130)
         const float4 c = C[i];
         const float4 m = mats[2 * (mk & MAT_MASK)];
@@ -545,10 +556,10 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
                                       f32x2{a0.z, a1.z}, f32x2{b0.x, b1.x}, f32x2{b0.y, b1.y}, f32x2{b0.z, b1.z},
                                       t_min, t_max, h, cnt);
             uint32_t ka = 7u, kb = 7u;
-            if (va) ka = finish_ray(mats, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0], h.prim[0], h.mk[0],
-                                    last_depth, sky_intensity);
-            if (vb) kb = finish_ray(mats, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1], h.prim[1], h.mk[1],
-                                    last_depth, sky_intensity);
+            if (va) ka = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0],
+                                    h.prim[0], last_depth, sky_intensity);
+            if (vb) kb = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1],
+                                    h.prim[1], last_depth, sky_intensity);
             enqueue(ka, ia);
             enqueue(kb, ib);
         }
@@ -560,9 +571,9 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
             if (valid) {
                 const float4 a = A[i], b = B[i];
                 float t = t_max;
-                uint32_t prim, mk;
-                closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, mk, cnt);
-                kind = finish_ray(mats, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, mk, last_depth,
+                uint32_t prim;
+                closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);
             }
             enqueue(kind, i);

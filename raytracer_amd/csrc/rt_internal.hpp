@@ -20,13 +20,15 @@ namespace rtamd {
 // is missed continues at its skip link (the entry after its subtree); a primitive continues
 // at i+1.  No stack, and every box test sees exactly the t_max the reference's recursion would.
 //
-// One entry = three float4 (48 bytes):
+// One entry = four float4 (64 bytes, so that an entry is one aligned 64-byte fetch: a single
+// s_load_dwordx16 for the wave sweep, one cache sector for the per-lane walk):
 //   box      a = (min.xyz , TAG_BOX<<30 | skip)   b = (max.xyz , 0)
-//   triangle a = (v0.xyz  , TAG_TRI<<30)          b = (e1.xyz  , prim_id)   c = (e2.xyz, matkind)
-//   sphere   a = (c.xyz   , TAG_SPH<<30)          b = (r, matkind, 0, prim_id)
-// e1 = v1 - v0 and e2 = v2 - v0 are the reference's v0v1 / v0v2 (shape.rs:417-418) computed
-// once instead of per test; matkind = material index | material kind << 28.
+//   triangle a = (v0.xyz  , TAG_TRI<<30)          b = (e1.xyz  , prim_id)   c = (e2.xyz, 0)
+//   sphere   a = (c.xyz   , TAG_SPH<<30)          b = (r, 0, 0, prim_id)
+// The fourth float4 is padding.  e1 = v1 - v0 and e2 = v2 - v0 are the reference's v0v1 / v0v2
+// (shape.rs:417-418) computed once instead of per test.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t ENTRY_FLOATS = 16;
 constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
 constexpr uint32_t TAG_SHIFT = 30;
 constexpr uint32_t SKIP_MASK = (1u << TAG_SHIFT) - 1u;
@@ -37,13 +39,13 @@ constexpr uint32_t PRIM_ID_MASK = 0x3FFFFFFFu;
 constexpr uint32_t META_SPHERE = 1u << 31;         // flag in prim_meta
 
 struct FlatScene {
-    std::vector<float> entries;        // 12 floats per entry
+    std::vector<float> entries;        // ENTRY_FLOATS per entry
     std::vector<float> prim_geo;       // 4 floats per primitive: tri (unit n0, 0) / sphere (c, r)
-    std::vector<uint32_t> prim_meta;   // material index | META_SPHERE
+    std::vector<uint32_t> prim_meta;   // material index | material kind << KIND_SHIFT | META_SPHERE
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
     bool has_spheres = false;
-    size_t n_entries() const { return entries.size() / 12; }
+    size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
     size_t n_prims() const { return prim_meta.size(); }
 };
 
@@ -63,7 +65,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
 // Device side
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
-    const void* entries;      // float4[3 * n_entries]
+    const void* entries;      // float4[4 * n_entries]
     const void* prim_geo;     // float4[n_prims]
     const uint32_t* prim_meta;
     const void* materials;    // float4[2 * n_mats]
