@@ -218,8 +218,9 @@ def main():
                 "traffic": measured_traffic() if args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size) else None,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
                 "algorithmic_bytes_per_launch": int(bytes_per_ray * rays / max(launches, 1)),
-                "note": "frac > 1: the tree (3.4 KB on this workload) is served from the scalar cache, the kernel is "
-                        "VALU-issue-bound (SQ_ACTIVE_INST_VALU ~ 98 % of SIMD cycles), not HBM-bound",
+                "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache; "
+                         "the kernel is instruction-issue-bound, not HBM-bound (profiles/r01_pmc_*)")
+                        if achieved and achieved > HBM_PEAK_GBS else "",
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "tests_per_ray": {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)},
                 "avg_launch_ms": round(ms_trace / max(launches, 1), 4), "launches": launches,

@@ -133,7 +133,9 @@ int get_events(Pipe& pp, size_t n) {
     return RT_OK;
 }
 
-constexpr size_t DEFAULT_MAX_PATHS = 16u << 20;
+// paths in flight over both pipelines: ~132 B of wavefront state each (8.4 GB of the 288 GB);
+// long launches amortise the tail in which the last waves of a kernel run alone
+constexpr size_t DEFAULT_MAX_PATHS = 64u << 20;
 
 }  // namespace
 
@@ -155,9 +157,10 @@ int rt_context_create(int device_id, rt_context** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
-    // four segments per wave slot of the chip (4 SIMDs x 8 waves per CU): segments differ in how
-    // long their paths live, and the surplus lets the dispatcher even that out
-    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 128u;
+    // two segments per wave slot of the chip (4 SIMDs x 8 waves per CU): segments differ in how
+    // long their paths live, and the surplus lets the dispatcher even that out (measured optimum
+    // on the Cornell workload: 8 Ki - 24 Ki segments of a 32 Mi-path batch)
+    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 64u;
     if (const char* e = std::getenv("RT_WAVE_TARGET")) {
         const long v = std::atol(e);
         if (v > 0) ctx->wave_target = (uint32_t)v;
