@@ -41,91 +41,108 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
 // (shape.rs:19-45) over the pre-order entry array.  best_t starts at the caller's t_max and is
 // the reference's narrowed t_max at every visit.
 // ---------------------------------------------------------------------------------------------
+// One ray of one lane during the per-lane walk.
+struct LaneRay {
+    float ox, oy, oz, dx, dy, dz;
+    float ix, iy, iz;          // math.rs:152: inv_d = 1.0 / ray_dir[axis], the same at every box
+    float best_t;              // the reference's narrowed t_max
+    uint32_t best_prim;        // prim id | PRIM_BACKFACE, RT_MISS while nothing is hit
+    uint32_t i;                // cursor into the entry array
+};
+
+__device__ __forceinline__ void lane_ray_init(LaneRay& r, float ox, float oy, float oz, float dx, float dy,
+                                              float dz, float t_max) {
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
+    r.best_t = t_max;
+    r.best_prim = RT_MISS;
+    r.i = 0;
+}
+
+// Visit the entry under the ray's cursor and move the cursor on.
+template <bool COUNT>
+__device__ __forceinline__ void visit_entry(const float4* __restrict__ ent, LaneRay& r, float t_min, Counts& cnt) {
+    const float EPS = 1.1920929e-7f;           // f32::EPSILON
+    const float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
+    const uint32_t i = r.i;
+    const float4 a = ent[4 * i];
+    const float4 b = ent[4 * i + 1];
+    const uint32_t w = f2u(a.w);
+    const uint32_t tag = w >> TAG_SHIFT;
+    if (tag == TAG_BOX) {
+        if (COUNT) cnt.box++;
+        // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
+        // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
+        // per-axis early return equals the one test after the third axis because t_min only
+        // grows and t_max only shrinks.
+        const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;   // math.rs:155
+        const float x0 = (a.x - ox) * r.ix, x1 = (b.x - ox) * r.ix;
+        const float y0 = (a.y - oy) * r.iy, y1 = (b.y - oy) * r.iy;
+        const float z0 = (a.z - oz) * r.iz, z1 = (b.z - oz) * r.iz;
+        const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
+        const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
+        r.i = tmx <= tmn ? (w & SKIP_MASK) : i + 1;
+    } else if (tag == TAG_TRI) {
+        if (COUNT) cnt.tri++;
+        const float4 c = ent[4 * i + 2];
+        // a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2
+        const float px = dy * c.z - dz * c.y;          // pvec = dir x v0v2
+        const float py = dz * c.x - dx * c.z;
+        const float pz = dx * c.y - dy * c.x;
+        const float det = dot3(b.x, b.y, b.z, px, py, pz);
+        if (!(fabsf(det) < EPS)) {
+            const float inv_det = 1.0f / det;
+            const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
+            const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+            if (!(u < 0.0f || u > 1.0f)) {
+                const float qx = ty * b.z - tz * b.y;  // qvec = tvec x v0v1
+                const float qy = tz * b.x - tx * b.z;
+                const float qz = tx * b.y - ty * b.x;
+                const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
+                if (!(v < 0.0f || u + v > 1.0f)) {
+                    const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
+                    if (t >= t_min && t < r.best_t) {  // shape.rs:297
+                        r.best_t = t;
+                        r.best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
+                    }
+                }
+            }
+        }
+        r.i = i + 1;
+    } else {
+        if (COUNT) cnt.sph++;
+        // a.xyz = centre, b.x = radius
+        const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
+        const float qa = dot3(dx, dy, dz, dx, dy, dz);
+        const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
+        const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
+        const float disc = half_b * half_b - qa * qc;
+        if (!(disc < 0.0f)) {
+            const float sqrtd = sqrtf(disc);
+            float root = (-half_b - sqrtd) / qa;
+            bool ok = true;
+            if (root < t_min || r.best_t < root) {     // shape.rs:32-36, closed interval
+                root = (-half_b + sqrtd) / qa;
+                if (root < t_min || r.best_t < root) ok = false;
+            }
+            if (ok) {
+                r.best_t = root;
+                r.best_prim = f2u(b.w);
+            }
+        }
+        r.i = i + 1;
+    }
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
-    // math.rs:152: inv_d = 1.0 / ray_dir[axis]; the same value at every box, so hoisted
-    const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
-    const float EPS = 1.1920929e-7f;           // f32::EPSILON
-    best_prim = RT_MISS;
-    uint32_t i = 0;
-    while (i < n_ent) {
-        const float4 a = ent[4 * i];
-        const float4 b = ent[4 * i + 1];
-        const uint32_t w = f2u(a.w);
-        const uint32_t tag = w >> TAG_SHIFT;
-        if (tag == TAG_BOX) {
-            if (COUNT) cnt.box++;
-            // math.rs:153-162.  The per-axis early return is equivalent to one test after the
-            // third axis: t_min only grows and t_max only shrinks.
-            float t0 = (a.x - ox) * ix, t1 = (b.x - ox) * ix;
-            float lo = ix < 0.0f ? t1 : t0, hi = ix < 0.0f ? t0 : t1;
-            float tmn = lo > t_min ? lo : t_min;
-            float tmx = hi < best_t ? hi : best_t;
-            bool miss = tmx <= tmn;
-            t0 = (a.y - oy) * iy; t1 = (b.y - oy) * iy;
-            lo = iy < 0.0f ? t1 : t0; hi = iy < 0.0f ? t0 : t1;
-            tmn = lo > tmn ? lo : tmn;
-            tmx = hi < tmx ? hi : tmx;
-            miss = miss || (tmx <= tmn);
-            t0 = (a.z - oz) * iz; t1 = (b.z - oz) * iz;
-            lo = iz < 0.0f ? t1 : t0; hi = iz < 0.0f ? t0 : t1;
-            tmn = lo > tmn ? lo : tmn;
-            tmx = hi < tmx ? hi : tmx;
-            miss = miss || (tmx <= tmn);
-            i = miss ? (w & SKIP_MASK) : i + 1;
-        } else if (tag == TAG_TRI) {
-            if (COUNT) cnt.tri++;
-            const float4 c = ent[4 * i + 2];
-            // a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2
-            const float px = dy * c.z - dz * c.y;          // pvec = dir x v0v2
-            const float py = dz * c.x - dx * c.z;
-            const float pz = dx * c.y - dy * c.x;
-            const float det = dot3(b.x, b.y, b.z, px, py, pz);
-            if (!(fabsf(det) < EPS)) {
-                const float inv_det = 1.0f / det;
-                const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-                const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
-                if (!(u < 0.0f || u > 1.0f)) {
-                    const float qx = ty * b.z - tz * b.y;  // qvec = tvec x v0v1
-                    const float qy = tz * b.x - tx * b.z;
-                    const float qz = tx * b.y - ty * b.x;
-                    const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
-                    if (!(v < 0.0f || u + v > 1.0f)) {
-                        const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-                        if (t >= t_min && t < best_t) {    // shape.rs:297
-                            best_t = t;
-                            best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
-                        }
-                    }
-                }
-            }
-            i = i + 1;
-        } else {
-            if (COUNT) cnt.sph++;
-            // a.xyz = centre, b.x = radius
-            const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
-            const float qa = dot3(dx, dy, dz, dx, dy, dz);
-            const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
-            const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
-            const float disc = half_b * half_b - qa * qc;
-            if (!(disc < 0.0f)) {
-                const float sqrtd = sqrtf(disc);
-                float root = (-half_b - sqrtd) / qa;
-                bool ok = true;
-                if (root < t_min || best_t < root) {       // shape.rs:32-36, closed interval
-                    root = (-half_b + sqrtd) / qa;
-                    if (root < t_min || best_t < root) ok = false;
-                }
-                if (ok) {
-                    best_t = root;
-                    best_prim = f2u(b.w);
-                }
-            }
-            i = i + 1;
-        }
-    }
+    LaneRay r;
+    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    while (r.i < n_ent) visit_entry<COUNT>(ent, r, t_min, cnt);
+    best_t = r.best_t;
+    best_prim = r.best_prim;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -564,6 +581,9 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
             enqueue(kb, ib);
         }
     } else {
+        // (Tried and measured slower on the 1-k-entry scenes: refilling idle lanes with the next
+        // rays of the segment, and a separate inner loop over boxes.  Both raise lane utilisation
+        // but cost more in lost coherence / waiting than they gain.)
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
             const bool valid = j0 + lane < n;
