@@ -70,7 +70,7 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(kind, width, height, depth, budget_s):
+def cpu_baseline(kind, width, height, depth, budget_s, gpu_render):
     """The oracle's tile-per-task renderer on the host cores, on a bounded sample of the workload
     (same scene and resolution, fewer samples per pixel)."""
     from oracle import binding as ob
@@ -87,7 +87,16 @@ def cpu_baseline(kind, width, height, depth, budget_s):
     # calibrate on 1 spp, then pick the spp that fills the budget
     _, _, st = osc.render(width, height, 1, depth, nthreads=threads, want_image=False)
     spp = int(max(1, min(64, budget_s / max(st["seconds"], 1e-3))))
-    _, _, st = osc.render(width, height, spp, depth, nthreads=threads, want_image=False)
+    acc, _, st = osc.render(width, height, spp, depth, nthreads=threads, want_image=False)
+    # image parity at matched spp: RMSE of the per-pixel mean radiance, GPU vs this oracle image,
+    # next to the oracle's own two-seed RMSE (the Monte-Carlo noise floor at this spp)
+    acc2, _, _ = osc.render(width, height, spp, depth, seed_offset=7919, nthreads=threads, want_image=False)
+    gpu = gpu_render(spp)
+    rm = lambda a, b: float(np.sqrt(np.mean((np.minimum(a, clip * spp) / spp - np.minimum(b, clip * spp) / spp) ** 2)))
+    clip = 4.0
+    image = {"spp": spp, "rmse_gpu_vs_oracle": round(rm(gpu, acc), 5), "rmse_oracle_vs_oracle": round(rm(acc2, acc), 5),
+             "clip": clip, "note": "linear per-pixel mean radiance, values clipped at 4 to tame fireflies; "
+                                   "bound used by the tests: gpu <= 1.15 x oracle-vs-oracle"}
     return {
         "value": round(st["rays"] / st["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
         "kind": "port",
@@ -95,6 +104,7 @@ def cpu_baseline(kind, width, height, depth, budget_s):
                   f"64x64 tiles, {st['rays']} rays in {st['seconds']:.1f} s",
         "box_tests_per_ray": round(st["box_tests"] / st["rays"], 2),
         "tri_tests_per_ray": round(st["tri_tests"] / st["rays"], 2),
+        "image_parity": image,
     }
 
 
@@ -229,7 +239,13 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(kind, width, height, depth, args.cpu_seconds)
+            def gpu_render(n_spp):
+                accum.zero_()
+                torch.cuda.synchronize()
+                p = wld.params(width, height, n_spp, depth, max_paths=args.max_paths)
+                wld.scene.render_device(cam, p, accum.data_ptr())
+                return accum.view(height, width, 3).cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(kind, width, height, depth, args.cpu_seconds, gpu_render)
         print(json.dumps(out), flush=True)
 
     if world > 1:
