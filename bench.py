@@ -60,12 +60,12 @@ def trace_bytes_per_ray(n_box, n_tri, n_sph):
     return 32.0 * n_box + 36.0 * n_tri + 16.0 * n_sph + 32.0 + 8.0 + 4.0
 
 
-def measured_traffic():
-    """HBM bytes per launch of the closest-hit kernel from the committed PMC passes (rocprofv3
-    cannot run inside this process); None when the file is absent."""
+def measured_traffic(key="hbm_bytes_per_launch"):
+    """HBM bytes per launch of the closest-hit kernel (or another figure) from the committed PMC
+    passes (rocprofv3 cannot run inside this process); None when the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)["k_trace"]["hbm_bytes_per_launch"]
+            return json.load(f)["k_trace"][key]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -209,6 +209,7 @@ def main():
         bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph)
         # rank 0's closest-hit kernel: algorithmic bytes of its launches / their summed duration
         achieved = bytes_per_ray * rays / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
+        headline = args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size)
         out = {
             "metric": "Mrays/sec (whole node), Cornell box 1024^2 1k spp",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -225,11 +226,12 @@ def main():
                 "bound": "hbm", "kernel": "k_trace (closest hit)",
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": measured_traffic() if args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size) else None,
+                "traffic": measured_traffic() if headline else None,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
+                "valu_issue_busy": measured_traffic("valu_issue_busy") if headline else None,
                 "algorithmic_bytes_per_launch": int(bytes_per_ray * rays / max(launches, 1)),
                 "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache; "
-                         "the kernel is instruction-issue-bound, not HBM-bound (profiles/r01_pmc_*)")
+                         "the kernel is VALU-issue-bound, not HBM-bound (valu_issue_busy, profiles/r01_pmc_sq.txt)")
                         if achieved and achieved > HBM_PEAK_GBS else "",
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "tests_per_ray": {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)},
