@@ -121,11 +121,14 @@ def main():
                     help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even for one rank")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep"], default="auto")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env(args.backend or None)
+    rank, world, local = D.init_from_env(args.backend or None, force=args.force_dist)
+    grouped = world > 1 or args.force_dist
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if local >= torch.cuda.device_count():      # several ranks on one GPU (tests only)
@@ -176,7 +179,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +200,7 @@ def main():
     stats = torch.tensor([elapsed, float(rays), ms_trace, float(launches)], dtype=torch.float64, device=dev)
     mx = stats.clone()
     sm = stats.clone()
-    if world > 1:
+    if grouped:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     elapsed_max = float(mx[0])
@@ -250,7 +253,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind, width, height, depth, args.cpu_seconds, gpu_render)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -297,6 +297,10 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
+    {
+        const char* e = getenv("RT_PRIM_WAIT");
+        s->dev.prim_wait = e ? (uint32_t)atoi(e) : 8u;   // 8: best of {1, 8, 16, 24, 40, 64} on the sphere and OBJ scenes
+    }
     s->dev.sweep = s->traversal == RT_TRAVERSAL_SWEEP ||
                    (s->traversal == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     // the host copies of the geometry are no longer needed

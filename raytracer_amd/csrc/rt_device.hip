@@ -59,88 +59,112 @@ __device__ __forceinline__ void lane_ray_init(LaneRay& r, float ox, float oy, fl
     r.i = 0;
 }
 
-// Visit the entry under the ray's cursor and move the cursor on.
-template <bool COUNT>
-__device__ __forceinline__ void visit_entry(const float4* __restrict__ ent, LaneRay& r, float t_min, Counts& cnt) {
+// math.rs:149-165 on the box held in (a, b); returns the ray's next cursor.
+// `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does fmaxf (likewise fminf); the
+// sign of a zero cannot change `t_max <= t_min`; and the per-axis early return equals the one
+// test after the third axis because t_min only grows and t_max only shrinks.
+__device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, const LaneRay& r, float t_min) {
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;       // math.rs:155
+    const float x0 = (a.x - r.ox) * r.ix, x1 = (b.x - r.ox) * r.ix;
+    const float y0 = (a.y - r.oy) * r.iy, y1 = (b.y - r.oy) * r.iy;
+    const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
+    const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
+    const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
+    return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : r.i + 1;
+}
+
+// shape.rs:411-450 on the triangle (a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2, b.w = prim id)
+__device__ __forceinline__ void tri_step(const float4& a, const float4& b, const float4& c, LaneRay& r, float t_min) {
     const float EPS = 1.1920929e-7f;           // f32::EPSILON
-    const float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
-    const uint32_t i = r.i;
-    const float4 a = ent[4 * i];
-    const float4 b = ent[4 * i + 1];
-    const uint32_t w = f2u(a.w);
-    const uint32_t tag = w >> TAG_SHIFT;
-    if (tag == TAG_BOX) {
-        if (COUNT) cnt.box++;
-        // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
-        // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
-        // per-axis early return equals the one test after the third axis because t_min only
-        // grows and t_max only shrinks.
-        const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;   // math.rs:155
-        const float x0 = (a.x - ox) * r.ix, x1 = (b.x - ox) * r.ix;
-        const float y0 = (a.y - oy) * r.iy, y1 = (b.y - oy) * r.iy;
-        const float z0 = (a.z - oz) * r.iz, z1 = (b.z - oz) * r.iz;
-        const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
-        const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
-        r.i = tmx <= tmn ? (w & SKIP_MASK) : i + 1;
-    } else if (tag == TAG_TRI) {
-        if (COUNT) cnt.tri++;
-        const float4 c = ent[4 * i + 2];
-        // a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2
-        const float px = dy * c.z - dz * c.y;          // pvec = dir x v0v2
-        const float py = dz * c.x - dx * c.z;
-        const float pz = dx * c.y - dy * c.x;
-        const float det = dot3(b.x, b.y, b.z, px, py, pz);
-        if (!(fabsf(det) < EPS)) {
-            const float inv_det = 1.0f / det;
-            const float tx = ox - a.x, ty = oy - a.y, tz = oz - a.z;
-            const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
-            if (!(u < 0.0f || u > 1.0f)) {
-                const float qx = ty * b.z - tz * b.y;  // qvec = tvec x v0v1
-                const float qy = tz * b.x - tx * b.z;
-                const float qz = tx * b.y - ty * b.x;
-                const float v = dot3(dx, dy, dz, qx, qy, qz) * inv_det;
-                if (!(v < 0.0f || u + v > 1.0f)) {
-                    const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-                    if (t >= t_min && t < r.best_t) {  // shape.rs:297
-                        r.best_t = t;
-                        r.best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
-                    }
+    const float px = r.dy * c.z - r.dz * c.y;          // pvec = dir x v0v2
+    const float py = r.dz * c.x - r.dx * c.z;
+    const float pz = r.dx * c.y - r.dy * c.x;
+    const float det = dot3(b.x, b.y, b.z, px, py, pz);
+    if (!(fabsf(det) < EPS)) {
+        const float inv_det = 1.0f / det;
+        const float tx = r.ox - a.x, ty = r.oy - a.y, tz = r.oz - a.z;
+        const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
+        if (!(u < 0.0f || u > 1.0f)) {
+            const float qx = ty * b.z - tz * b.y;  // qvec = tvec x v0v1
+            const float qy = tz * b.x - tx * b.z;
+            const float qz = tx * b.y - ty * b.x;
+            const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
+            if (!(v < 0.0f || u + v > 1.0f)) {
+                const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
+                if (t >= t_min && t < r.best_t) {  // shape.rs:297
+                    r.best_t = t;
+                    r.best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
                 }
             }
         }
-        r.i = i + 1;
-    } else {
-        if (COUNT) cnt.sph++;
-        // a.xyz = centre, b.x = radius
-        const float ocx = ox - a.x, ocy = oy - a.y, ocz = oz - a.z;
-        const float qa = dot3(dx, dy, dz, dx, dy, dz);
-        const float half_b = dot3(ocx, ocy, ocz, dx, dy, dz);
-        const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
-        const float disc = half_b * half_b - qa * qc;
-        if (!(disc < 0.0f)) {
-            const float sqrtd = sqrtf(disc);
-            float root = (-half_b - sqrtd) / qa;
-            bool ok = true;
-            if (root < t_min || r.best_t < root) {     // shape.rs:32-36, closed interval
-                root = (-half_b + sqrtd) / qa;
-                if (root < t_min || r.best_t < root) ok = false;
-            }
-            if (ok) {
-                r.best_t = root;
-                r.best_prim = f2u(b.w);
-            }
-        }
-        r.i = i + 1;
     }
 }
 
+// shape.rs:19-45 on the sphere (a.xyz = centre, b.x = radius, b.w = prim id)
+__device__ __forceinline__ void sphere_step(const float4& a, const float4& b, LaneRay& r, float t_min) {
+    const float ocx = r.ox - a.x, ocy = r.oy - a.y, ocz = r.oz - a.z;
+    const float qa = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
+    const float half_b = dot3(ocx, ocy, ocz, r.dx, r.dy, r.dz);
+    const float qc = dot3(ocx, ocy, ocz, ocx, ocy, ocz) - b.x * b.x;
+    const float disc = half_b * half_b - qa * qc;
+    if (!(disc < 0.0f)) {
+        const float sqrtd = sqrtf(disc);
+        float root = (-half_b - sqrtd) / qa;
+        bool ok = true;
+        if (root < t_min || r.best_t < root) {     // shape.rs:32-36, closed interval
+            root = (-half_b + sqrtd) / qa;
+            if (root < t_min || r.best_t < root) ok = false;
+        }
+        if (ok) {
+            r.best_t = root;
+            r.best_prim = f2u(b.w);
+        }
+    }
+}
+
+// Per-lane walk of a whole wave (call converged; lanes without a ray pass valid = false).  Every
+// lane visits its own entries in the reference's order.  A lane that stands at a primitive waits
+// there while boxes remain to be tested by other lanes, until prim_wait lanes stand at
+// primitives (or no lane stands at a box): the long primitive routines then run with many lanes
+// instead of once per loop trip for a few.
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, float ox,
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, uint32_t prim_wait,
+                                            bool valid, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
-    while (r.i < n_ent) visit_entry<COUNT>(ent, r, t_min, cnt);
+    bool live = valid && n_ent > 0;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+    if (live) { a = ent[0]; b = ent[1]; }
+    for (;;) {
+        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
+        const bool at_box = live && tag == TAG_BOX;
+        const bool at_prim = live && tag != TAG_BOX;
+        const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
+        if ((mb | mp) == 0ull) break;
+        if (at_box) {
+            if (COUNT) cnt.box++;
+            r.i = box_step(a, b, r, t_min);
+            live = r.i < n_ent;
+            if (live) { a = ent[4 * r.i]; b = ent[4 * r.i + 1]; }
+        }
+        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
+            if (at_prim) {
+                if (tag == TAG_TRI) {
+                    if (COUNT) cnt.tri++;
+                    const float4 c = ent[4 * r.i + 2];
+                    tri_step(a, b, c, r, t_min);
+                } else {
+                    if (COUNT) cnt.sph++;
+                    sphere_step(a, b, r, t_min);
+                }
+                r.i = r.i + 1;
+                live = r.i < n_ent;
+                if (live) { a = ent[4 * r.i]; b = ent[4 * r.i + 1]; }
+            }
+        }
+    }
     best_t = r.best_t;
     best_prim = r.best_prim;
 }
@@ -369,13 +393,20 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             if (vb) write_hit(sc, out, rb, o1[0], o1[1], o1[2], d1[0], d1[1], d1[2], h.t[1], h.prim[1]);
         }
     } else {
-        for (size_t r = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; r < n; r += (size_t)gridDim.x * RT_BLOCK) {
-            const float ox = rays[r * 6 + 0], oy = rays[r * 6 + 1], oz = rays[r * 6 + 2];
-            const float dx = rays[r * 6 + 3], dy = rays[r * 6 + 4], dz = rays[r * 6 + 5];
+        // whole waves enter the walk together; the lanes past the end carry no ray
+        const size_t stride = (size_t)gridDim.x * RT_BLOCK;
+        for (size_t r0 = (size_t)blockIdx.x * RT_BLOCK; r0 < n; r0 += stride) {
+            const size_t r = r0 + threadIdx.x;
+            const bool valid = r < n;
+            float ox = 0.0f, oy = 0.0f, oz = 0.0f, dx = 1.0f, dy = 1.0f, dz = 1.0f;
+            if (valid) {
+                ox = rays[r * 6 + 0]; oy = rays[r * 6 + 1]; oz = rays[r * 6 + 2];
+                dx = rays[r * 6 + 3]; dy = rays[r * 6 + 4]; dz = rays[r * 6 + 5];
+            }
             float t = t_max;
             uint32_t prim;
-            closest_hit<COUNT>(ent, sc.n_entries, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
-            write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
+            closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
     if (COUNT) {
@@ -582,20 +613,19 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         }
     } else {
         // (Tried and measured slower on the 1-k-entry scenes: refilling idle lanes with the next
-        // rays of the segment, and a separate inner loop over boxes.  Both raise lane utilisation
-        // but cost more in lost coherence / waiting than they gain.)
+        // rays of the segment.)
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
             const bool valid = j0 + lane < n;
             uint32_t kind = 7u;
-            if (valid) {
-                const float4 a = A[i], b = B[i];
-                float t = t_max;
-                uint32_t prim;
-                closest_hit<COUNT>(ent, sc.n_entries, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            if (valid) { a = A[i]; b = B[i]; }
+            float t = t_max;
+            uint32_t prim;
+            closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            if (valid)
                 kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);
-            }
             enqueue(kind, i);
         }
     }

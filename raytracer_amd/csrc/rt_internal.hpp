@@ -75,6 +75,7 @@ struct DevScene {
     uint32_t kinds_present;
     uint32_t sweep;           // 1: wave-synchronous sweep of the entry array, 0: per-lane walk
     uint32_t has_spheres;     // the scene holds at least one sphere
+    uint32_t prim_wait;       // per-lane walk: lanes that must stand at primitives before their routine runs
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

@@ -9,12 +9,14 @@ import torch.distributed as dist
 from .partition import partition
 
 
-def init_from_env(backend=None):
-    """(rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1."""
+def init_from_env(backend=None, force=False):
+    """(rank, world_size, local_rank); initialises the default process group when WORLD_SIZE > 1
+    (or for a single rank too when `force` is set: the collectives then run through the backend
+    as they would on a node, which is how the RCCL path is exercised on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -28,8 +30,8 @@ def init_from_env(backend=None):
 
 
 def reduce_to_root(accum):
-    """Sum the per-rank accumulation buffers into rank 0's (in place).  No-op for one rank."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """Sum the per-rank accumulation buffers into rank 0's (in place).  No-op without a process group."""
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
     return accum
 

@@ -14,11 +14,11 @@ from helpers import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _run(n):
+def _run(n, backend="gloo", extra=()):
     args = ["--steps", "1", "--warmup", "0", "--workload", "thing_glass_2048_512", "--size", "160x136",
-            "--spp", "12", "--no-cpu", "--gpus", str(n)]
-    env = dict(os.environ, RT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if n == 1:
+            "--spp", "12", "--no-cpu", "--gpus", str(n)] + list(extra)
+    env = dict(os.environ, RT_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n == 1 and not extra:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
@@ -39,3 +39,13 @@ def test_two_and_four_ranks_match_one_rank():
         assert many["config"]["rays_per_step"] == one["config"]["rays_per_step"]
         assert many["config"]["accum_sum"] == pytest.approx(one["config"]["accum_sum"], rel=1e-5)
         assert many["roofline"]["achieved"] is not None and "cpu_baseline" not in many
+
+
+def test_one_rank_through_rccl():
+    """The barrier, the reduce and the all-reduces of the N>1 path on the nccl (= RCCL) backend,
+    with the single rank this box can hold, launched exactly as a node run is launched."""
+    one = _run(1)
+    rccl = _run(1, backend="nccl", extra=["--force-dist"])
+    assert rccl["n_gpus"] == 1
+    assert rccl["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+    assert rccl["config"]["accum_sum"] == one["config"]["accum_sum"]
