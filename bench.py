@@ -94,9 +94,13 @@ def cpu_baseline(kind, width, height, depth, budget_s, gpu_render):
     gpu = gpu_render(spp)
     rm = lambda a, b: float(np.sqrt(np.mean((np.minimum(a, clip * spp) / spp - np.minimum(b, clip * spp) / spp) ** 2)))
     clip = 4.0
+    tm = lambda a: np.minimum(np.sqrt(np.maximum(a / spp, 0.0)), 1.0)          # main.rs:369-373 before the 8-bit pack
+    rt_ = lambda a, b: float(np.sqrt(np.mean((tm(a) - tm(b)) ** 2)))
     image = {"spp": spp, "rmse_gpu_vs_oracle": round(rm(gpu, acc), 5), "rmse_oracle_vs_oracle": round(rm(acc2, acc), 5),
-             "clip": clip, "note": "linear per-pixel mean radiance, values clipped at 4 to tame fireflies; "
-                                   "bound used by the tests: gpu <= 1.15 x oracle-vs-oracle"}
+             "tonemapped_rmse_gpu_vs_oracle": round(rt_(gpu, acc), 5),
+             "tonemapped_rmse_oracle_vs_oracle": round(rt_(acc2, acc), 5),
+             "clip": clip, "note": "linear per-pixel mean radiance (values clipped at 4 to tame fireflies) and "
+                                   "tonemapped [0,1] values; bound used by the tests: gpu <= 1.10 x oracle-vs-oracle"}
     return {
         "value": round(st["rays"] / st["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
         "kind": "port",
