@@ -132,13 +132,21 @@ int rt_scene_add_spheres(rt_scene* scene, const rt_sphere* spheres, size_t n);
  * identity; only the identity is supported (every shipped scene uses Mat4::identity()). */
 int rt_scene_add_mesh(rt_scene* scene, const rt_triangle* tris, size_t n, const float* xform);
 int rt_scene_set_root(rt_scene* scene, int root_kind);
-/* How the closest-hit kernel walks the flattened trees.  Both forms visit the same entries in
- * the same order with the same arithmetic as the reference's recursion (shape.rs:142-158,
- * 292-324) and give bit-identical hits; they differ in speed only.  PER_LANE: every lane
- * follows its own cursor (any scene size).  SWEEP: the wave sweeps the entry array once with
- * scalar fetches (small scenes).  AUTO picks by scene size.  May be called before or after
- * rt_scene_commit(). */
-enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2 };
+/* How the closest-hit kernel walks the flattened trees.  PER_LANE and SWEEP visit the same
+ * entries in the same order with the same arithmetic as the reference's recursion
+ * (shape.rs:142-158, 292-324) and give bit-identical hits; they differ in speed only.
+ * PER_LANE: every lane follows its own cursor (any scene size).  SWEEP: the wave sweeps the
+ * entry array once with scalar fetches (small scenes).  AUTO picks one of these two by scene
+ * size.
+ * ORDERED is opt-in and has no counterpart in the reference: the same trees, the same box and
+ * primitive tests, but at every box the child nearer along the ray is visited first (per-lane
+ * stack), so the narrowed t_max culls far more boxes.  The closest hit is the same primitive and
+ * the same t unless two primitives tie in t or a box test and a primitive test disagree within
+ * rounding (the reference resolves both by its visiting order); it is therefore not exact by
+ * construction.  Fails with RT_ERR_UNSUPPORTED for scenes of 2^29 entries or more, or boxes
+ * nested deeper than 64.
+ * May be called before or after rt_scene_commit(). */
+enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2, RT_TRAVERSAL_ORDERED = 3 };
 int rt_scene_set_traversal(rt_scene* scene, int mode);
 /* builds the reference-topology BVHs (shape.rs:94-138, 264-290), flattens them and uploads */
 int rt_scene_commit(rt_scene* scene);

@@ -5,8 +5,10 @@ this module only marshals numpy arrays and device pointers across the C ABI.  Th
 fallback: if the library is missing the import fails, and every call that needs a GPU raises
 RtError when the HIP runtime reports none.
 """
+import atexit
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -25,7 +27,7 @@ ASSET_DIR = os.path.join(_HERE, "assets")
 MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
-TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP = 0, 1, 2
+TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS = 1, 2
 DEFAULT_SEED = 0x9E3779B97F4A7C15
@@ -139,6 +141,25 @@ HOST_SYMBOLS = [
 ]
 
 
+# Handles still open when the interpreter exits are closed here, scenes and worlds before their
+# contexts, while the HIP runtime is still up (object finalisation order at exit is arbitrary).
+_live = weakref.WeakSet()
+
+
+def _close_all():
+    objs = list(_live)
+    for rank in (0, 1):
+        for o in objs:
+            if isinstance(o, Context) == bool(rank):
+                try:
+                    o.close()
+                except Exception:
+                    pass
+
+
+atexit.register(_close_all)
+
+
 def _check(rc):
     if rc != 0:
         raise RtError(f"rt error {rc}: {lib.rt_last_error().decode(errors='replace')}")
@@ -156,6 +177,7 @@ class Context:
         _check(lib.rt_context_create(device_id, C.byref(h)))
         self.h = h
         self.device_id = device_id
+        _live.add(self)
 
     def close(self):
         if getattr(self, "h", None):
@@ -203,6 +225,7 @@ class Scene:
         h = C.c_void_p()
         _check(lib.rt_scene_create(ctx.h if ctx is not None else None, C.byref(h)))
         self.h = h
+        _live.add(self)
         m = np.ascontiguousarray(materials, dtype=material_dt)
         _check(lib.rt_scene_set_materials(self.h, _ptr(m), len(m)))
         for kind, arr in objects:
@@ -292,6 +315,7 @@ class World:
         self.ctx = ctx
         self.h = handle
         self.scene = Scene._borrow(ctx, lib.rt_world_scene(handle))
+        _live.add(self)
 
     @staticmethod
     def _make(ctx, fn, *args):

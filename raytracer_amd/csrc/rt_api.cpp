@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -75,6 +76,11 @@ struct rt_context {
     uint32_t wave_target = 8192;
     int n_pipes = 2;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The owner holds one reference and every scene created on the context another, so a scene
+    // destroyed after rt_context_destroy() still finds its device and streams; work on a
+    // destroyed context is refused.
+    std::atomic<int> refs{1};
+    bool destroyed = false;
 
     LaunchCfg cfg(int pipe = 0) const { return LaunchCfg{(void*)pipes[pipe].stream, grid_cap, wave_target}; }
     ~rt_context() {
@@ -94,6 +100,7 @@ struct rt_scene {
     std::vector<SceneObject> objects;
     int root_kind = RT_ROOT_BVH;
     int traversal = RT_TRAVERSAL_AUTO;
+    bool ordered_ok = false;
     bool committed = false;
     FlatScene flat;
     DeviceBuffer d_entries, d_geo, d_meta, d_mats;
@@ -103,8 +110,16 @@ struct rt_scene {
 namespace {
 
 int set_device(rt_context* ctx) {
+    if (ctx->destroyed) return fail(RT_ERR_STATE, "the context of this scene has been destroyed");
     HIP_TRY(hipSetDevice(ctx->device));
     return RT_OK;
+}
+
+void release_context(rt_context* ctx) {
+    if (ctx->refs.fetch_sub(1) == 1) {
+        (void)hipSetDevice(ctx->device);
+        delete ctx;
+    }
 }
 
 int ensure_capacity(rt_context* ctx, Pipe& pp, size_t paths, size_t n_seg) {
@@ -179,9 +194,12 @@ int rt_context_create(int device_id, rt_context** out) {
 
 void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
+    if (ctx->destroyed) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    delete ctx;
+    for (int i = 0; i < ctx->n_pipes; i++)
+        if (ctx->pipes[i].stream) (void)hipStreamSynchronize(ctx->pipes[i].stream);
+    ctx->destroyed = true;
+    release_context(ctx);
 }
 
 void* rt_context_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
@@ -197,18 +215,23 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
     // ctx may be NULL: the scene is then host-only (it can be committed and its flattened
     // entries inspected, but nothing can be traced or rendered with it)
     if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: NULL argument");
+    if (ctx && ctx->destroyed) return fail(RT_ERR_STATE, "rt_scene_create: the context has been destroyed");
     *out = new rt_scene();
     (*out)->ctx = ctx;
+    if (ctx) ctx->refs.fetch_add(1);
     return RT_OK;
 }
 
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
-    if (scene->ctx) {
-        (void)hipSetDevice(scene->ctx->device);
-        (void)hipStreamSynchronize(scene->ctx->stream);
+    rt_context* ctx = scene->ctx;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        for (int i = 0; i < ctx->n_pipes; i++)
+            if (ctx->pipes[i].stream) (void)hipStreamSynchronize(ctx->pipes[i].stream);
     }
-    delete scene;
+    delete scene;                              // frees the scene's device arrays
+    if (ctx) release_context(ctx);
 }
 
 int rt_scene_set_materials(rt_scene* s, const rt_material* mats, size_t n) {
@@ -253,13 +276,24 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
     return RT_OK;
 }
 
+// the kernel form a committed scene is traced with
+static int apply_traversal(rt_scene* s, int mode) {
+    if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
+        return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
+    s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
+    s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
+                   (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
+    return RT_OK;
+}
+
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
-    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_SWEEP) return fail(RT_ERR_INVALID, "unknown traversal mode");
+    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_ORDERED) return fail(RT_ERR_INVALID, "unknown traversal mode");
+    if (s->committed) {
+        int rc = apply_traversal(s, mode);
+        if (rc) return rc;
+    }
     s->traversal = mode;
-    if (s->committed)
-        s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
-                       (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     return RT_OK;
 }
 
@@ -271,6 +305,8 @@ int rt_scene_commit(rt_scene* s) {
     rt_context* ctx = s->ctx;
     s->dev.n_entries = (uint32_t)s->flat.n_entries();
     s->dev.n_prims = (uint32_t)s->flat.n_prims();
+    s->ordered_ok = s->flat.ordered_ok;
+    s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
     if (!ctx) {                                // host-only scene: keep the flattened arrays
         s->committed = true;
         return RT_OK;
@@ -301,8 +337,8 @@ int rt_scene_commit(rt_scene* s) {
         const char* e = getenv("RT_PRIM_WAIT");
         s->dev.prim_wait = e ? (uint32_t)atoi(e) : 8u;   // 8: best of {1, 8, 16, 24, 40, 64} on the sphere and OBJ scenes
     }
-    s->dev.sweep = s->traversal == RT_TRAVERSAL_SWEEP ||
-                   (s->traversal == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
+    rc = apply_traversal(s, s->traversal);
+    if (rc) return rc;
     // the host copies of the geometry are no longer needed
     for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
     s->flat.entries.clear(); s->flat.entries.shrink_to_fit();

@@ -182,6 +182,55 @@ struct Builder {
     }
 };
 
+// Child links for the ordered walk (rt_internal.hpp: ORD_*), derived from the finished entry
+// array: a box's first child is the next entry; it has a second child when the first child's
+// subtree ends before the box's own skip link.  Also measures the nesting depth of the boxes.
+void annotate_children(FlatScene& out) {
+    const size_t n = out.n_entries();
+    out.ordered_ok = n <= ORD_RIGHT_MASK;
+    auto word = [&](size_t i, int k) { uint32_t u; std::memcpy(&u, &out.entries[i * ENTRY_FLOATS + k], 4); return u; };
+    auto is_box = [&](size_t i) { return (word(i, 3) >> TAG_SHIFT) == TAG_BOX; };
+    auto end_of = [&](size_t i) { return is_box(i) ? (size_t)(word(i, 3) & SKIP_MASK) : i + 1; };
+    // 2 x centre of an entry's bounds (only differences along one axis are compared)
+    auto centre2 = [&](size_t i, float c[3]) {
+        const float* e = &out.entries[i * ENTRY_FLOATS];
+        const uint32_t tag = word(i, 3) >> TAG_SHIFT;
+        for (int k = 0; k < 3; k++) {
+            if (tag == TAG_BOX) c[k] = e[k] + e[4 + k];
+            else if (tag == TAG_SPH) c[k] = 2.0f * e[k];
+            else {
+                const float p1 = e[k] + e[4 + k], p2 = e[k] + e[8 + k];
+                c[k] = std::min(e[k], std::min(p1, p2)) + std::max(e[k], std::max(p1, p2));
+            }
+        }
+    };
+    std::vector<size_t> open_until;            // skip links of the boxes the cursor is inside
+    uint32_t depth = 0;
+    for (size_t i = 0; i < n; i++) {
+        while (!open_until.empty() && open_until.back() <= i) open_until.pop_back();
+        if (!is_box(i)) continue;
+        const size_t end = word(i, 3) & SKIP_MASK;
+        open_until.push_back(end);
+        depth = std::max<uint32_t>(depth, (uint32_t)open_until.size());
+        uint32_t link = 0;
+        if (i + 1 < end) {
+            const size_t second = end_of(i + 1);
+            if (second < end && out.ordered_ok) {
+                float c1[3], c2[3];
+                centre2(i + 1, c1);
+                centre2(second, c2);
+                int axis = 0;
+                for (int k = 1; k < 3; k++)
+                    if (std::fabs(c1[k] - c2[k]) > std::fabs(c1[axis] - c2[axis])) axis = k;
+                link = (uint32_t)second | ((uint32_t)axis << ORD_AXIS_SHIFT) | (c1[axis] <= c2[axis] ? ORD_FIRST_LOWER : 0u);
+            }
+        }
+        std::memcpy(&out.entries[i * ENTRY_FLOATS + 7], &link, 4);
+    }
+    out.depth = depth;
+    if (depth > ORDERED_MAX_DEPTH) out.ordered_ok = false;
+}
+
 }  // namespace
 
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
@@ -252,6 +301,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
         return "unknown root kind";
     }
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
+    annotate_children(out);
     return std::string();
 }
 

@@ -169,6 +169,93 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     best_prim = r.best_prim;
 }
 
+// math.rs:149-165 as a predicate (the same arithmetic as box_step)
+__device__ __forceinline__ bool box_hit(const float4& a, const float4& b, const LaneRay& r, float t_min) {
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+    const float x0 = (a.x - r.ox) * r.ix, x1 = (b.x - r.ox) * r.ix;
+    const float y0 = (a.y - r.oy) * r.iy, y1 = (b.y - r.oy) * r.iy;
+    const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
+    const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
+    const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
+    return !(tmx <= tmn);
+}
+
+// Ordered walk (opt-in; not the reference's visiting order): the same entries and the same tests,
+// but at a box with two children the child that lies first along the ray is visited first and
+// the other one waits on the lane's stack, so best_t has usually shrunk by the time it is popped
+// and its box test fails.  `stack` is this wave's LDS region, slot s of a lane at
+// stack[s * 64 + lane] (conflict-free whatever the lanes' depths); the host guarantees
+// stack_depth slots suffice (a slot per box nesting level).  Top-level entries (a list root has
+// several) are taken in array order whenever the stack runs empty.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ ent, uint32_t n_ent, uint32_t prim_wait,
+                                                    uint32_t* stack, uint32_t lane, bool valid, float ox, float oy,
+                                                    float oz, float dx, float dy, float dz, float t_min,
+                                                    float& best_t, uint32_t& best_prim, Counts& cnt) {
+    LaneRay r;
+    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    uint32_t sp = 0;                           // slots in use
+    uint32_t top = 0;                          // next top-level entry
+    bool live = false;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+    // next entry to visit: the youngest waiting child, else the next top-level entry
+    auto pop = [&]() {
+        const bool from_top = sp == 0;
+        if (from_top) r.i = top;
+        else { sp--; r.i = stack[sp * 64u + lane]; }
+        live = r.i < n_ent;
+        if (live) {
+            a = ent[4 * r.i];
+            b = ent[4 * r.i + 1];
+            if (from_top) top = (f2u(a.w) >> TAG_SHIFT) == TAG_BOX ? (f2u(a.w) & SKIP_MASK) : r.i + 1;
+        }
+    };
+    if (valid) pop();
+    for (;;) {
+        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
+        const bool at_box = live && tag == TAG_BOX;
+        const bool at_prim = live && tag != TAG_BOX;
+        const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
+        if ((mb | mp) == 0ull) break;
+        if (at_box) {
+            if (COUNT) cnt.box++;
+            if (box_hit(a, b, r, t_min)) {
+                const uint32_t link = f2u(b.w);
+                const uint32_t second = link & ORD_RIGHT_MASK;
+                uint32_t next = r.i + 1;
+                if (second != 0u) {
+                    const uint32_t axis = (link >> ORD_AXIS_SHIFT) & 3u;
+                    const float d = axis == 0u ? dx : (axis == 1u ? dy : dz);
+                    const bool first_is_near = (d >= 0.0f) == ((link & ORD_FIRST_LOWER) != 0u);
+                    stack[sp * 64u + lane] = first_is_near ? second : next;
+                    sp++;
+                    next = first_is_near ? next : second;
+                }
+                r.i = next;
+                a = ent[4 * next];
+                b = ent[4 * next + 1];
+            } else {
+                pop();
+            }
+        }
+        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
+            if (at_prim) {
+                if (tag == TAG_TRI) {
+                    if (COUNT) cnt.tri++;
+                    const float4 c = ent[4 * r.i + 2];
+                    tri_step(a, b, c, r, t_min);
+                } else {
+                    if (COUNT) cnt.sph++;
+                    sphere_step(a, b, r, t_min);
+                }
+                pop();
+            }
+        }
+    }
+    best_t = r.best_t;
+    best_prim = r.best_prim;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Closest hit, wave-synchronous form for small scenes.  Skip links only point forward, so a
 // wave can sweep the entry array ONCE in order: entry e is fetched with scalar loads into
@@ -367,14 +454,18 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
     out[r] = h;
 }
 
-// SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene)
+// per-lane stacks of the ordered walk: stack_depth * 64 words per wave (dynamic LDS)
+extern __shared__ uint32_t lds_stack[];
+
+// SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene),
+//        3 = ordered per-lane walk
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
             rt_hit* __restrict__ out, Totals* totals) {
     const float4* ent = (const float4*)sc.entries;
     Counts cnt{0, 0, 0};
-    if (SWEEP) {
+    if (SWEEP == 1 || SWEEP == 2) {
         // the same two-rays-per-lane sweep the renderer uses; every wave takes 128 consecutive rays
         const size_t wave = (size_t)blockIdx.x * (RT_BLOCK / 64) + (threadIdx.x >> 6);
         const size_t n_waves = (size_t)gridDim.x * (RT_BLOCK / 64);
@@ -405,7 +496,12 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             }
             float t = t_max;
             uint32_t prim;
-            closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            if (SWEEP == 3)
+                closest_hit_ordered<COUNT>(ent, sc.n_entries, sc.prim_wait,
+                                           lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, threadIdx.x & 63u,
+                                           valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            else
+                closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
@@ -590,7 +686,7 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         pos = wave_append(kind == 2u, n2);
         if (kind == 2u) q2[base + pos] = i;
     };
-    if (SWEEP) {
+    if (SWEEP == 1 || SWEEP == 2) {
         // two rays per lane: rays j0 + lane and j0 + 64 + lane
         for (uint32_t j0 = 0; j0 < n; j0 += 128u) {
             const uint32_t ia = base + j0 + lane, ib = ia + 64u;
@@ -622,7 +718,12 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
             if (valid) { a = A[i]; b = B[i]; }
             float t = t_max;
             uint32_t prim;
-            closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            if (SWEEP == 3)
+                closest_hit_ordered<COUNT>(ent, sc.n_entries, sc.prim_wait,
+                                           lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, lane, valid, a.x,
+                                           a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else
+                closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
                 kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);
@@ -820,11 +921,13 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t grid = grid_for(n, cfg.grid_cap);
+    const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
 #define RT_TRACE_API(CNT, SWP)                                                                          \
-    hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), 0, st, sc, (const float*)d_rays, n, \
+    hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), lds, st, sc, (const float*)d_rays, n, \
                        t_min, t_max, (rt_hit*)d_hits, d_counts)
-    const int mode = sc.sweep ? (sc.has_spheres ? 2 : 1) : 0;
-    if (mode == 2) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
+    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
+    if (mode == 3) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
+    else if (mode == 2) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
     else if (mode == 1) { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
 #undef RT_TRACE_API
@@ -843,13 +946,15 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
                  uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
+    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
 #define RT_TRACE(CNT, SWP)                                                                              \
-    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), 0, st, sc, g, (const float4*)rb.cur.A, \
+    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
                        rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
                        last_depth ? 1u : 0u, t_min, sky_intensity)
-    const int mode = sc.sweep ? (sc.has_spheres ? 2 : 1) : 0;
-    if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
+    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
+    if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
+    else if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
     else if (mode == 1) { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
 #undef RT_TRACE

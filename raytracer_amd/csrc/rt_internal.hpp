@@ -32,6 +32,14 @@ constexpr uint32_t ENTRY_FLOATS = 16;
 constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
 constexpr uint32_t TAG_SHIFT = 30;
 constexpr uint32_t SKIP_MASK = (1u << TAG_SHIFT) - 1u;
+// Box entries, fourth float of the second float4 (unused by the reference-order walks): links for
+// the ordered walk.  Bits 0-28: entry index of the second child (0: the box has one child; the
+// first child is always the next entry); bits 29-30: the axis along which the two children are
+// furthest apart; bit 31: the first child is the lower one along that axis.
+constexpr uint32_t ORD_RIGHT_MASK = (1u << 29) - 1u;
+constexpr uint32_t ORD_AXIS_SHIFT = 29;
+constexpr uint32_t ORD_FIRST_LOWER = 1u << 31;
+constexpr uint32_t ORDERED_MAX_DEPTH = 64;   // 4 waves x 64 lanes x 64 slots x 4 B = 64 KB of LDS per workgroup
 constexpr uint32_t KIND_SHIFT = 28;
 constexpr uint32_t MAT_MASK = (1u << KIND_SHIFT) - 1u;
 constexpr uint32_t PRIM_BACKFACE = 1u << 31;       // flag in the compact hit record
@@ -45,6 +53,8 @@ struct FlatScene {
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
     bool has_spheres = false;
+    uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
+    bool ordered_ok = false;           // box entries carry the child links of the ordered walk
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
     size_t n_prims() const { return prim_meta.size(); }
 };
@@ -76,6 +86,8 @@ struct DevScene {
     uint32_t sweep;           // 1: wave-synchronous sweep of the entry array, 0: per-lane walk
     uint32_t has_spheres;     // the scene holds at least one sphere
     uint32_t prim_wait;       // per-lane walk: lanes that must stand at primitives before their routine runs
+    uint32_t ordered;         // 1: near-child-first walk with a per-lane stack (not the reference's visiting order)
+    uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

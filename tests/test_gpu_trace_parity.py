@@ -140,3 +140,16 @@ def test_empty_batch_and_errors(rt, ob, ctx):
         sp = np.zeros(1, dtype=rt.sphere_dt)
         sp["mat"] = 3                                             # out of range
         rt.Scene(ctx, mats, [("spheres", sp)])
+
+
+def test_context_destroyed_before_its_scene(rt, ob):
+    """Destroy order is the caller's choice: a scene outlives rt_context_destroy() safely, refuses
+    work afterwards, and frees its device arrays when it is destroyed in turn."""
+    ctx2 = rt.Context(0)
+    sc = mirror(rt, ctx2, ob.Scene.world1())
+    rays = random_rays(ob, 3, 1000, -6.0, 6.0)
+    assert len(sc.trace(rays)) == 1000
+    ctx2.close()
+    with pytest.raises(rt.RtError):
+        sc.trace(rays)
+    sc.close()

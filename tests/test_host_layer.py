@@ -152,6 +152,57 @@ def _dot(a, b):
     return F(F(a[0] * b[0]) + F(a[1] * b[1])) + F(a[2] * b[2])
 
 
+def _box_miss(e, o, inv, t_min, best_t):
+    tmn, tmx = F(t_min), best_t
+    for k in range(3):
+        t0 = F(F(e[k] - o[k]) * inv[k])
+        t1 = F(F(e[4 + k] - o[k]) * inv[k])
+        if inv[k] < 0:
+            t0, t1 = t1, t0
+        tmn = t0 if t0 > tmn else tmn
+        tmx = t1 if t1 < tmx else tmx
+        if tmx <= tmn:
+            return True
+    return False
+
+
+def _prim_test(e, tag, prim, o, d, t_min, best_t, best):
+    eps = F(1.1920929e-7)
+    if tag == 1:
+        v0, e1, e2 = e[0:3], e[4:7], e[8:11]
+        p = [F(F(d[1] * e2[2]) - F(d[2] * e2[1])), F(F(d[2] * e2[0]) - F(d[0] * e2[2])),
+             F(F(d[0] * e2[1]) - F(d[1] * e2[0]))]
+        det = _dot(e1, p)
+        if not (abs(det) < eps):
+            invd = F(1.0) / det
+            tv = [F(o[k] - v0[k]) for k in range(3)]
+            u = F(_dot(tv, p) * invd)
+            if not (u < 0 or u > 1):
+                q = [F(F(tv[1] * e1[2]) - F(tv[2] * e1[1])), F(F(tv[2] * e1[0]) - F(tv[0] * e1[2])),
+                     F(F(tv[0] * e1[1]) - F(tv[1] * e1[0]))]
+                v = F(_dot(d, q) * invd)
+                if not (v < 0 or F(u + v) > 1):
+                    t = F(_dot(e2, q) * invd)
+                    if t >= t_min and t < best_t:
+                        return t, prim
+        return best_t, best
+    c, r = e[0:3], e[4]
+    oc = [F(o[k] - c[k]) for k in range(3)]
+    a = _dot(d, d)
+    hb = _dot(oc, d)
+    cc = F(_dot(oc, oc) - F(r * r))
+    disc = F(F(hb * hb) - F(a * cc))
+    if not (disc < 0):
+        sq = np.sqrt(disc)
+        root = F(F(-hb - sq) / a)
+        if root < t_min or best_t < root:
+            root = F(F(-hb + sq) / a)
+            if root < t_min or best_t < root:
+                return best_t, best
+        return root, prim
+    return best_t, best
+
+
 def _walk(entries, o, d, t_min, t_max):
     """Pre-order walk with skip links, f32 arithmetic; mirrors the device loop."""
     ent_u = entries.view(np.uint32)
@@ -160,62 +211,56 @@ def _walk(entries, o, d, t_min, t_max):
         inv = [F(1.0) / d[k] for k in range(3)]
         best_t, best = F(t_max), 0xFFFFFFFF
         i = 0
-        eps = F(1.1920929e-7)
         while i < n:
             e = entries[i]
             w = int(ent_u[i, 3])
             tag = w >> 30
             if tag == 0:
-                tmn, tmx = F(t_min), best_t
-                miss = False
-                for k in range(3):
-                    t0 = F(F(e[k] - o[k]) * inv[k])
-                    t1 = F(F(e[4 + k] - o[k]) * inv[k])
-                    if inv[k] < 0:
-                        t0, t1 = t1, t0
-                    tmn = t0 if t0 > tmn else tmn
-                    tmx = t1 if t1 < tmx else tmx
-                    if tmx <= tmn:
-                        miss = True
-                        break
-                i = (w & 0x3FFFFFFF) if miss else i + 1
-            elif tag == 1:
-                v0, e1, e2 = e[0:3], e[4:7], e[8:11]
-                p = [F(F(d[1] * e2[2]) - F(d[2] * e2[1])), F(F(d[2] * e2[0]) - F(d[0] * e2[2])),
-                     F(F(d[0] * e2[1]) - F(d[1] * e2[0]))]
-                det = _dot(e1, p)
-                if not (abs(det) < eps):
-                    invd = F(1.0) / det
-                    tv = [F(o[k] - v0[k]) for k in range(3)]
-                    u = F(_dot(tv, p) * invd)
-                    if not (u < 0 or u > 1):
-                        q = [F(F(tv[1] * e1[2]) - F(tv[2] * e1[1])), F(F(tv[2] * e1[0]) - F(tv[0] * e1[2])),
-                             F(F(tv[0] * e1[1]) - F(tv[1] * e1[0]))]
-                        v = F(_dot(d, q) * invd)
-                        if not (v < 0 or F(u + v) > 1):
-                            t = F(_dot(e2, q) * invd)
-                            if t >= t_min and t < best_t:
-                                best_t, best = t, int(ent_u[i, 7])
-                i += 1
+                i = (w & 0x3FFFFFFF) if _box_miss(e, o, inv, t_min, best_t) else i + 1
             else:
-                c, r = e[0:3], e[4]
-                oc = [F(o[k] - c[k]) for k in range(3)]
-                a = _dot(d, d)
-                hb = _dot(oc, d)
-                cc = F(_dot(oc, oc) - F(r * r))
-                disc = F(F(hb * hb) - F(a * cc))
-                if not (disc < 0):
-                    sq = np.sqrt(disc)
-                    root = F(F(-hb - sq) / a)
-                    ok = True
-                    if root < t_min or best_t < root:
-                        root = F(F(-hb + sq) / a)
-                        if root < t_min or best_t < root:
-                            ok = False
-                    if ok:
-                        best_t, best = root, int(ent_u[i, 7])
+                best_t, best = _prim_test(e, tag, int(ent_u[i, 7]), o, d, t_min, best_t, best)
                 i += 1
     return best, best_t
+
+
+def _walk_ordered(entries, o, d, t_min, t_max):
+    """The opt-in ordered walk: same tests, nearer child first, the other child on a stack."""
+    ent_u = entries.view(np.uint32)
+    n = len(entries)
+    visits = 0
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = [F(1.0) / d[k] for k in range(3)]
+        best_t, best = F(t_max), 0xFFFFFFFF
+        top, stack = 0, []
+        while True:
+            if stack:
+                i = stack.pop()
+            elif top < n:
+                i = top
+                w = int(ent_u[i, 3])
+                top = (w & 0x3FFFFFFF) if (w >> 30) == 0 else i + 1
+            else:
+                break
+            while True:
+                visits += 1
+                e = entries[i]
+                w = int(ent_u[i, 3])
+                tag = w >> 30
+                if tag != 0:
+                    best_t, best = _prim_test(e, tag, int(ent_u[i, 7]), o, d, t_min, best_t, best)
+                    break
+                if _box_miss(e, o, inv, t_min, best_t):
+                    break
+                link = int(ent_u[i, 7])
+                second = link & 0x1FFFFFFF
+                nxt = i + 1
+                if second:
+                    axis = (link >> 29) & 3
+                    first_is_near = (d[axis] >= 0) == bool(link >> 31)
+                    stack.append(second if first_is_near else nxt)
+                    nxt = nxt if first_is_near else second
+                i = nxt
+    return best, best_t, visits
 
 
 @pytest.mark.parametrize("root", [0, 2])
@@ -233,6 +278,40 @@ def test_flattened_entries_encode_reference_traversal(rt, ob, root):
         if prim != 0xFFFFFFFF:
             assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
     assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+
+
+def test_child_links_of_the_ordered_walk(rt, ob):
+    """Box entries carry (second child, axis, first-child-is-lower); the ordered walk over them
+    finds the reference's hits on a scene without coincident primitives, with fewer visits."""
+    mats, objects, _ = random_scene(ob, 21, n_spheres=40, n_meshes=2, tris_per_mesh=60, extent=6.0)
+    osc = ob.Scene.from_description(mats, objects, 0)
+    ent = rt.Scene(None, mats, objects, 0).entries()
+    u = ent.view(np.uint32)
+    n = len(ent)
+    end_of = lambda i: int(u[i, 3] & 0x3FFFFFFF) if (u[i, 3] >> 30) == 0 else i + 1
+    two = 0
+    for i in range(n):
+        if (u[i, 3] >> 30) != 0:
+            continue
+        end, link = end_of(i), int(u[i, 7])
+        second = link & 0x1FFFFFFF
+        if i + 1 < end and end_of(i + 1) < end:
+            assert second == end_of(i + 1) and end_of(second) == end         # exactly two children
+            assert ((link >> 29) & 3) < 3
+            two += 1
+        else:
+            assert link == 0
+    assert two > 50
+    rays = random_rays(ob, 8, 300, -7.0, 7.0)
+    want, st = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    visits = 0
+    for k in range(len(rays)):
+        prim, t, v = _walk_ordered(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))
+        visits += v
+        assert prim == want["prim_id"][k]
+        if prim != 0xFFFFFFFF:
+            assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
+    assert visits < st["box_tests"] + st["tri_tests"] + st["sph_tests"]
 
 
 def test_entry_layout_small_cases(rt, ob):
@@ -256,5 +335,9 @@ def test_entry_layout_small_cases(rt, ob):
     np.testing.assert_array_equal(ent[0, 4:7], np.float32([1, 1, 2]) + np.float32(0.0001))
     np.testing.assert_array_equal(ent[2, 0:3], np.float32([0, 0, 1]) - np.float32(0.0001))
     assert ent.shape[1] == 16 and not ent[:, 12:].any()               # 64-byte entries, last float4 is padding
+    # child links of the ordered walk: box 0 = {t0 | box 2}, box 2 = {t2 | t1}; z separates both pairs
+    assert [int(x & 0x1FFFFFFF) for x in u[[0, 2], 7]] == [2, 4]
+    assert [int((x >> 29) & 3) for x in u[[0, 2], 7]] == [2, 2]
+    assert [int(x >> 31) for x in u[[0, 2], 7]] == [1, 0]
     np.testing.assert_array_equal(ent[1, 4:7], [1, 0, 0])              # v0v1
     np.testing.assert_array_equal(ent[1, 8:11], [0, 1, 0])             # v0v2
