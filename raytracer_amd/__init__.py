@@ -21,7 +21,7 @@ except ImportError:  # a torch-free process uses the system runtime the library 
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(_HERE, "librt_amd.so")   # override: A/B runs of kernel builds
 ASSET_DIR = os.path.join(_HERE, "assets")
 
 MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3

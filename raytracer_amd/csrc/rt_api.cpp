@@ -73,7 +73,7 @@ struct rt_context {
     uint32_t grid_cap = 2048;
     Pipe pipes[2];
     DeviceBuffer totals, scratch_in, scratch_out;
-    uint32_t wave_target = 8192;
+    uint32_t wave_target = 8192, wave_target_sweep = 8192;
     int n_pipes = 2;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // The owner holds one reference and every scene created on the context another, so a scene
@@ -172,13 +172,15 @@ int rt_context_create(int device_id, rt_context** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
-    // two segments per wave slot of the chip (4 SIMDs x 8 waves per CU): segments differ in how
-    // long their paths live, and the surplus lets the dispatcher even that out (measured optimum
-    // on the Cornell workload: 8 Ki - 24 Ki segments of a 32 Mi-path batch)
+    // Segments (= waves) per batch.  Per-lane walk: two per wave slot of the chip (4 SIMDs x 8
+    // waves per CU); segments differ in how long their paths live and the surplus lets the
+    // dispatcher even that out.  Wave sweep: one per wave slot (its waves cost the same whatever
+    // their rays do).  Measured optima on the sphere / OBJ scenes and on the plane Cornell box.
     ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 64u;
+    ctx->wave_target_sweep = (uint32_t)std::max(1, prop.multiProcessorCount) * 32u;
     if (const char* e = std::getenv("RT_WAVE_TARGET")) {
         const long v = std::atol(e);
-        if (v > 0) ctx->wave_target = (uint32_t)v;
+        if (v > 0) ctx->wave_target = ctx->wave_target_sweep = (uint32_t)v;
     }
     for (Pipe& pp : ctx->pipes) {
         HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
@@ -457,7 +459,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
     }
-    const uint32_t wave_target = ctx->wave_target;
+    const uint32_t wave_target = s->dev.sweep ? ctx->wave_target_sweep : ctx->wave_target;
     auto segments = [&](BatchGeom& g) {        // one wave per segment, a multiple of 64 slots long
         g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + wave_target - 1) / wave_target + 63u) / 64u * 64u);
         g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;

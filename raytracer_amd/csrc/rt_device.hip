@@ -22,7 +22,9 @@
 namespace rtamd {
 
 #define RT_BLOCK 256   // grid-stride kernels
-#define RT_WAVE 256    // segment kernels: workgroup size (every wave owns one segment)
+#ifndef RT_WAVE
+#define RT_WAVE 64     // segment kernels: workgroup size (every wave owns one segment; one wave per
+#endif                 // workgroup lets the dispatcher refill wave slots one by one: +3 % over 256)
 #define RT_WPB (RT_WAVE / 64)
 
 struct Counts { uint32_t box, tri, sph; };
@@ -326,22 +328,32 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
     float bt0 = t_max, bt1 = t_max;
     uint32_t bp0 = RT_MISS, bp1 = RT_MISS;
     uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
-    for (uint32_t e = 0;; e++) {
-        // next entry that some lane stands on: a scalar scan that leaves the vector state alone;
-        // on0 / on1 = lanes whose ray 0 / ray 1 is at entry e
-        unsigned long long on0, on1;
+    // next entry at or after e that some lane stands on: a scalar scan that leaves the vector
+    // state alone; on0 / on1 = lanes whose ray 0 / ray 1 is at that entry
+    unsigned long long on0, on1;
+    uint32_t e = 0;
+    auto scan = [&]() {
         for (;;) {
             on0 = __ballot(cur0 == e);
             on1 = __ballot(cur1 == e);
             if ((on0 | on1) != 0ull || e >= n_ent) break;
             e++;
         }
-        if (e >= n_ent) break;
+    };
+    scan();
+    // (the loop tests at the bottom, after the state update, so that the only values alive on the
+    // back edge are the updated ones and they keep their registers)
+    if (e < n_ent) do {
         const f32x16 E = ent[e];                       // one s_load_dwordx16
         const uint32_t w = f2u(E[3]);
         const uint32_t tag = w >> TAG_SHIFT;
-        // What the entry does to a lane that is on it; the state is written after the branches.
-        uint32_t nxt0 = e + 1u, nxt1 = e + 1u;
+        // What the entry does to a lane that is on it.  The state is written once, after the
+        // branches (a box leaves hit0 / hit1 empty and the candidate values undefined): with a
+        // single update per trip the state keeps its registers around the loop.
+        uint32_t nxt0, nxt1;
+        unsigned long long hit0 = 0ull, hit1 = 0ull;
+        float nt0, nt1;
+        uint32_t np0, np1;
         if (tag == TAG_BOX) {
             if (COUNT) cnt.box += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
             // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
@@ -358,10 +370,9 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
             const uint32_t skip = w & SKIP_MASK;
             nxt0 = tmx0 <= tmn0 ? skip : e + 1u;
             nxt1 = tmx1 <= tmn1 ? skip : e + 1u;
+            asm("" : "=v"(nt0), "=v"(nt1), "=v"(np0), "=v"(np1));   // no candidate: any register will do
         } else {
-            unsigned long long hit0, hit1;
-            float nt0, nt1;
-            uint32_t np0, np1;
+            nxt0 = nxt1 = e + 1u;
             if (!SPHERES || tag == TAG_TRI) {
                 if (COUNT) cnt.tri += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
                 // E[0..2] = v0, E[4..6] = v0v1, E[8..10] = v0v2
@@ -385,14 +396,19 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
                 const f32x2 t = dot3s(E[8], E[9], E[10], qx, qy, qz) * inv_det;
                 const f32x2 uv = u + v;
                 // the reference's early returns (shape.rs:428-445) and acceptance test (shape.rs:297)
-                hit0 = on0 & __ballot(!(fabsf(det.x) < EPS) & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) &
-                                      !(uv.x > 1.0f) & (t.x >= t_min) & (t.x < bt0));
-                hit1 = on1 & __ballot(!(fabsf(det.y) < EPS) & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) &
-                                      !(uv.y > 1.0f) & (t.y >= t_min) & (t.y < bt1));
+                // (one ballot per comparison, combined in scalar registers: each is a single
+                // compare that writes its lane mask)
+                hit0 = on0 & __ballot(!(fabsf(det.x) < EPS)) & __ballot(!(u.x < 0.0f)) & __ballot(!(u.x > 1.0f)) &
+                       __ballot(!(v.x < 0.0f)) & __ballot(!(uv.x > 1.0f)) & __ballot(t.x >= t_min) & __ballot(t.x < bt0);
+                hit1 = on1 & __ballot(!(fabsf(det.y) < EPS)) & __ballot(!(u.y < 0.0f)) & __ballot(!(u.y > 1.0f)) &
+                       __ballot(!(v.y < 0.0f)) & __ballot(!(uv.y > 1.0f)) & __ballot(t.y >= t_min) & __ballot(t.y < bt1);
                 const uint32_t id = f2u(E[7]);
                 nt0 = t.x; nt1 = t.y;
-                np0 = id | (det.x < EPS ? PRIM_BACKFACE : 0u);
-                np1 = id | (det.y < EPS ? PRIM_BACKFACE : 0u);
+                // shape.rs:424: backface = det < EPS.  An accepted hit has |det| >= EPS (and a NaN
+                // det gives a NaN t, never accepted), so there the flag is det's sign bit.
+                static_assert(PRIM_BACKFACE == 0x80000000u, "the backface flag is the sign bit");
+                np0 = id | (f2u(det.x) & PRIM_BACKFACE);
+                np1 = id | (f2u(det.y) & PRIM_BACKFACE);
             } else {
                 if (COUNT) cnt.sph += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
                 // E[0..2] = centre, E[4] = radius
@@ -413,14 +429,16 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
                 nt0 = b00 ? r1.x : r0.x;
                 nt1 = b10 ? r1.y : r0.y;
             }
-            select_into(bt0, nt0, hit0);
-            select_into(bt1, nt1, hit1);
-            select_into(bp0, np0, hit0);
-            select_into(bp1, np1, hit1);
         }
+        select_into(bt0, nt0, hit0);
+        select_into(bt1, nt1, hit1);
+        select_into(bp0, np0, hit0);
+        select_into(bp1, np1, hit1);
         select_into(cur0, nxt0, on0);
         select_into(cur1, nxt1, on1);
-    }
+        e++;
+        scan();
+    } while (e < n_ent);
     h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1;
 }
 
