@@ -65,17 +65,20 @@ struct Pipe {
     size_t capacity = 0;
     std::vector<hipEvent_t> events;     // profiling pool
     hipEvent_t accum_done = nullptr;    // this pipe's last accumulate
+    hipEvent_t joined = nullptr;        // end of this pipe's work in a render call
 };
+
+constexpr int MAX_PIPES = 4;
 
 struct rt_context {
     int device = 0;
     hipStream_t stream = nullptr;       // = pipes[0].stream: the stream callers may order work on
     uint32_t grid_cap = 2048;
-    Pipe pipes[2];
+    Pipe pipes[MAX_PIPES];
     DeviceBuffer totals, scratch_in, scratch_out;
     uint32_t wave_target = 8192, wave_target_sweep = 8192;
     int n_pipes = 2;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr;
     // The owner holds one reference and every scene created on the context another, so a scene
     // destroyed after rt_context_destroy() still finds its device and streams; work on a
     // destroyed context is refused.
@@ -87,10 +90,10 @@ struct rt_context {
         for (Pipe& p : pipes) {
             for (hipEvent_t e : p.events) (void)hipEventDestroy(e);
             if (p.accum_done) (void)hipEventDestroy(p.accum_done);
+            if (p.joined) (void)hipEventDestroy(p.joined);
             if (p.stream) (void)hipStreamDestroy(p.stream);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_join) (void)hipEventDestroy(ev_join);
     }
 };
 
@@ -185,11 +188,11 @@ int rt_context_create(int device_id, rt_context** out) {
     for (Pipe& pp : ctx->pipes) {
         HIP_TRY(hipStreamCreateWithFlags(&pp.stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&pp.accum_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&pp.joined, hipEventDisableTiming));
     }
     ctx->stream = ctx->pipes[0].stream;
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::atoi(e) == 1 ? 1 : 2;
+    if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::min(MAX_PIPES, std::max(1, std::atoi(e)));
     *out = ctx.release();
     return RT_OK;
 }
@@ -445,16 +448,16 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     const uint32_t n_samples = p->sample_end - p->sample_begin;
     size_t max_paths = p->max_paths_in_flight ? p->max_paths_in_flight : DEFAULT_MAX_PATHS;
     if (max_paths < 64) max_paths = 64;
-    // batch = (a run of whole tiles) x (a run of samples); with more than one batch, two are kept
-    // in flight, so each gets half of the path budget
+    // batch = (a run of whole tiles) x (a run of samples); with more than one batch, n_pipes are
+    // kept in flight, so each gets its share of the path budget
     size_t tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
     uint32_t samples_per_batch =
         (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
     size_t n_batches = ((n_tiles + tiles_per_batch - 1) / tiles_per_batch) *
                        ((n_samples + samples_per_batch - 1) / samples_per_batch);
-    const int n_pipes = (n_batches > 1 && ctx->n_pipes > 1) ? 2 : 1;
-    if (n_pipes == 2) {
-        max_paths = std::max<size_t>(64, max_paths / 2);
+    const int n_pipes = (int)std::min<size_t>(n_batches, (size_t)ctx->n_pipes);
+    if (n_pipes > 1) {
+        max_paths = std::max<size_t>(64, max_paths / (size_t)n_pipes);
         tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
@@ -476,11 +479,11 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
 
     hipStream_t st0 = ctx->pipes[0].stream;
     struct Span { size_t e0, e1; int what; };
-    std::vector<Span> spans[2];
-    size_t ev_used[2] = {0, 0};
+    std::vector<Span> spans[MAX_PIPES];
+    size_t ev_used[MAX_PIPES] = {};
     double ms_by_kind[2] = {0.0, 0.0};
-    auto fold_spans = [&]() -> int {           // needs both streams to be idle
-        for (int k = 0; k < 2; k++) {
+    auto fold_spans = [&]() -> int {           // needs every stream to be idle
+        for (int k = 0; k < MAX_PIPES; k++) {
             for (const Span& sp : spans[k]) {
                 float m = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->pipes[k].events[sp.e0], ctx->pipes[k].events[sp.e1]));
@@ -497,9 +500,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     HIP_TRY(hipEventCreate(&ev_begin));
     HIP_TRY(hipEventCreate(&ev_end));
     HIP_TRY(hipEventRecord(ev_begin, st0));
-    if (n_pipes == 2) {                        // the second stream starts after whatever precedes the call
+    if (n_pipes > 1) {                         // the other streams start after whatever precedes the call
         HIP_TRY(hipEventRecord(ctx->ev_fork, st0));
-        HIP_TRY(hipStreamWaitEvent(ctx->pipes[1].stream, ctx->ev_fork, 0));
+        for (int k = 1; k < n_pipes; k++) HIP_TRY(hipStreamWaitEvent(ctx->pipes[k].stream, ctx->ev_fork, 0));
     }
 
     uint64_t trace_launches = 0;
@@ -563,7 +566,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 cur ^= 1;
                 bind();
             }
-            // batches add to the same pixels: accumulate in batch order, across the two streams
+            // batches add to the same pixels: accumulate in batch order, across the streams
             if (last_pipe >= 0 && last_pipe != k)
                 HIP_TRY(hipStreamWaitEvent(st, ctx->pipes[last_pipe].accum_done, 0));
             if (launch_accumulate(cfg, g, rb, d_accum, p->max_bounces))
@@ -578,9 +581,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             }
         }
     }
-    if (n_pipes == 2) {                        // join: everything is complete when stream 0 is
-        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->pipes[1].stream));
-        HIP_TRY(hipStreamWaitEvent(st0, ctx->ev_join, 0));
+    for (int k = 1; k < n_pipes; k++) {        // join: everything is complete when stream 0 is
+        HIP_TRY(hipEventRecord(ctx->pipes[k].joined, ctx->pipes[k].stream));
+        HIP_TRY(hipStreamWaitEvent(st0, ctx->pipes[k].joined, 0));
     }
     HIP_TRY(hipEventRecord(ev_end, st0));
 

@@ -679,8 +679,17 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
 // ---------------------------------------------------------------------------------------------
 // trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
 // ---------------------------------------------------------------------------------------------
+// Register budget of the trace kernel: 8 waves per SIMD need at most 64 VGPRs and, because a wave's
+// SGPR allocation is rounded up to 16 and carries 16 more, at most 80 SGPRs (96 would admit 6).
+// The traversal is latency-bound (a wave issues vector work during a fifth of its lifetime), so
+// resident waves are what fills the SIMD.  The SGPR cap makes the compiler park the kernel
+// arguments that are only used after the walk in lanes of a spare VGPR instead of holding them
+// in SGPRs across it; nothing is spilled inside the walk.
+#ifndef RT_TRACE_SGPRS
+#define RT_TRACE_SGPRS 80
+#endif
 template <bool COUNT, int SWEEP>
-__global__ void __launch_bounds__(RT_WAVE)
+__global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
         uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf,
