@@ -110,6 +110,10 @@ struct rt_scene {
     DevScene dev{};
 };
 
+#ifdef RT_STAMPS
+namespace rtamd { void dump_stamps(); }
+#endif
+
 namespace {
 
 int set_device(rt_context* ctx) {
@@ -606,6 +610,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     }
     (void)hipEventDestroy(ev_begin);
     (void)hipEventDestroy(ev_end);
+#ifdef RT_STAMPS
+    { static bool dumped = false; if (!dumped && !count) { dumped = true; rtamd::dump_stamps(); } }
+#endif
     return RT_OK;
 }
 

@@ -16,6 +16,11 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#ifdef RT_STAMPS
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#endif
 
 #include "rt_internal.hpp"
 
@@ -688,17 +693,31 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
 #ifndef RT_TRACE_SGPRS
 #define RT_TRACE_SGPRS 80
 #endif
+#ifdef RT_STAMPS
+// Diagnostic build only (-DRT_STAMPS): start / end time and placement of every wave of the first
+// few trace launches, dumped by the host to the file named by RT_STAMPS_FILE
+// (tools/stamps_report.py reads it).
+constexpr uint32_t STAMP_SLOTS = 32, STAMP_WAVES = 16384;
+__device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
+#endif
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
         uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf,
         const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ qcnt, Totals* totals,
-        uint32_t last_depth, float t_min, float sky_intensity) {
+        uint32_t last_depth, float t_min, float sky_intensity
+#ifdef RT_STAMPS
+        , uint32_t stamp_slot
+#endif
+        ) {
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
     const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (seg >= g.n_seg) return;
+#ifdef RT_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t base = seg * g.seg_len;
     const uint32_t n = segcnt[seg];
     const float t_max = __builtin_inff();                  // main.rs:46: t_max = f32::INFINITY
@@ -762,6 +781,15 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         qcnt[g.n_seg + seg] = n1;
         qcnt[2u * g.n_seg + seg] = n2;
     }
+#ifdef RT_STAMPS
+    if (lane == 0 && stamp_slot < STAMP_SLOTS && seg < STAMP_WAVES) {
+        unsigned long long* o = rt_stamps + ((size_t)stamp_slot * STAMP_WAVES + seg) * 4;
+        o[0] = stamp_t0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID, all 32 bits
+        o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | n;   // HW_REG_XCC_ID | rays
+    }
+#endif
     if (COUNT) {
         atomicAdd(&totals->box, (unsigned long long)cnt.box);
         atomicAdd(&totals->tri, (unsigned long long)cnt.tri);
@@ -978,7 +1006,14 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
     hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
                        rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
-                       last_depth ? 1u : 0u, t_min, sky_intensity)
+                       last_depth ? 1u : 0u, t_min, sky_intensity RT_STAMP_ARG)
+#ifdef RT_STAMPS
+    static uint32_t stamped_launches = 0;
+    const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
+#define RT_STAMP_ARG , stamp_slot
+#else
+#define RT_STAMP_ARG
+#endif
     const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
     if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
     else if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
@@ -987,6 +1022,17 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
 #undef RT_TRACE
     return check_launch();
 }
+
+#ifdef RT_STAMPS
+void dump_stamps() {
+    const char* path = getenv("RT_STAMPS_FILE");
+    if (!path) return;
+    std::vector<unsigned long long> h((size_t)STAMP_SLOTS * STAMP_WAVES * 4);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(rt_stamps), h.size() * 8);
+    if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+}
+#endif
 
 int launch_shade(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
                  uint32_t depth) {

@@ -1,0 +1,110 @@
+// Issue cost of the vector instructions the sweep kernel is made of, on this GPU: cycles of one
+// SIMD per wave64 instruction with 1, 2, 4 and 8 resident waves per SIMD, each wave running a
+// long stream of independent instructions of one kind.  Build: hipcc --offload-arch=gfx950 -O2
+// tools/valu_rate.hip -o tools/valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+#define REP8(x) x x x x x x x x
+constexpr int ITERS = 4096;    // x 64 instructions per iteration
+
+template <int KIND>
+__global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * 0.5f, b5 = a5 * 0.5f, b6 = a6 * 0.5f, b7 = a7 * 0.5f;
+    const float m = 1.0000001f;
+    unsigned long long mask = 0x5555555555555555ull;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < ITERS; i++) {
+        if (KIND == 0) {         // v_fma_f32
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 1) {  // v_pk_mul_f32 on register pairs
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7}, mm = {m, m};
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                              "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(mm));)
+            a0 = p0.x; a1 = p1.x; a2 = p2.x; a3 = p3.x; a4 = p4.x; a5 = p5.x; a6 = p6.x; a7 = p7.x;
+            b0 = p0.y; b1 = p1.y; b2 = p2.y; b3 = p3.y; b4 = p4.y; b5 = p5.y; b6 = p6.y; b7 = p7.y;
+        } else if (KIND == 2) {  // v_cndmask_b32 with the lane mask in SGPRs
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                              "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(mask));)
+        } else if (KIND == 3) {  // v_cmp_lt_f32 writing a lane mask to SGPRs
+            unsigned long long m0, m1, m2, m3;
+            REP8(asm volatile("v_cmp_lt_f32_e64 %0, %4, %5\n v_cmp_lt_f32_e64 %1, %5, %6\n v_cmp_lt_f32_e64 %2, %6, %7\n v_cmp_lt_f32_e64 %3, %7, %4\n"
+                              "v_cmp_lt_f32_e64 %0, %4, %6\n v_cmp_lt_f32_e64 %1, %5, %7\n v_cmp_lt_f32_e64 %2, %6, %4\n v_cmp_lt_f32_e64 %3, %7, %5"
+                              : "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));)
+            mask ^= m0 ^ m1 ^ m2 ^ m3;
+        } else if (KIND == 4) {  // v_min3_f32
+            REP8(asm volatile("v_min3_f32 %0, %0, %8, %8\n v_min3_f32 %1, %1, %8, %8\n v_min3_f32 %2, %2, %8, %8\n v_min3_f32 %3, %3, %8, %8\n"
+                              "v_min3_f32 %4, %4, %8, %8\n v_min3_f32 %5, %5, %8, %8\n v_min3_f32 %6, %6, %8, %8\n v_min3_f32 %7, %7, %8, %8"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (KIND == 6) {  // s_and_b64 (scalar ALU)
+            unsigned long long s0 = mask, s1 = mask + 1, s2 = mask + 2, s3 = mask + 3, s4 = mask + 4, s5 = mask + 5, s6 = mask + 6, s7 = mask + 7;
+            REP8(asm volatile("s_and_b64 %0, %0, %8\n s_and_b64 %1, %1, %8\n s_and_b64 %2, %2, %8\n s_and_b64 %3, %3, %8\n"
+                              "s_and_b64 %4, %4, %8\n s_and_b64 %5, %5, %8\n s_and_b64 %6, %6, %8\n s_and_b64 %7, %7, %8"
+                              : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "s"(mask) : "scc");)
+            mask ^= s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;
+        } else if (KIND == 7) {  // alternating v_fma_f32 / s_and_b64 in one wave
+            unsigned long long s0 = mask, s1 = mask + 1, s2 = mask + 2, s3 = mask + 3;
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n s_and_b64 %4, %4, %9\n v_fma_f32 %1, %1, %8, %8\n s_and_b64 %5, %5, %9\n"
+                              "v_fma_f32 %2, %2, %8, %8\n s_and_b64 %6, %6, %9\n v_fma_f32 %3, %3, %8, %8\n s_and_b64 %7, %7, %9"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(m), "s"(mask) : "scc");)
+            mask ^= s0 ^ s1 ^ s2 ^ s3;
+        } else if (KIND == 5) {  // v_pk_mul_f32 with one scalar-register operand pair
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %1, %1, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %2, %2, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %3, %3, %8 op_sel_hi:[1,0]\n"
+                              "v_pk_mul_f32 %4, %4, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %5, %5, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %6, %6, %8 op_sel_hi:[1,0]\n v_pk_mul_f32 %7, %7, %8 op_sel_hi:[1,0]"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(mask));)
+            a0 = p0.x; a1 = p1.x; a2 = p2.x; a3 = p3.x; a4 = p4.x; a5 = p5.x; a6 = p6.x; a7 = p7.x;
+            b0 = p0.y; b1 = p1.y; b2 = p2.y; b3 = p3.y; b4 = p4.y; b5 = p5.y; b6 = p6.y; b7 = p7.y;
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7 + (float)(mask & 1);
+    if (threadIdx.x == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+template <int KIND>
+static void run(const char* name, int simds, float* out, unsigned long long* clk) {
+    for (int w : {1, 2, 4, 8}) {
+        const int blocks = simds * w;
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f);   // warm
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f);
+        hipDeviceSynchronize();
+        static unsigned long long h[2 * 8192];
+        hipMemcpy(h, clk, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
+        double cyc = 0, real = 0;
+        for (int b = 0; b < blocks; b++) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
+        cyc /= blocks; real /= blocks;
+        const double n_inst = (double)ITERS * 64;
+        printf("%-28s waves/SIMD %d: %.2f cycles per instruction per wave, %.2f SIMD cycles per instruction, clock %.2f GHz\n",
+               name, w, cyc / n_inst, cyc / n_inst / w, cyc / real * 0.1);
+    }
+}
+
+int main() {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int simds = p.multiProcessorCount * 4;
+    float* out; unsigned long long* clk;
+    hipMalloc(&out, sizeof(float) * 64 * simds * 8);
+    hipMalloc(&clk, sizeof(unsigned long long) * 2 * simds * 8);
+    run<0>("v_fma_f32", simds, out, clk);
+    run<1>("v_pk_mul_f32", simds, out, clk);
+    run<5>("v_pk_mul_f32 (sgpr operand)", simds, out, clk);
+    run<2>("v_cndmask_b32 (sgpr mask)", simds, out, clk);
+    run<3>("v_cmp_lt_f32 -> sgpr", simds, out, clk);
+    run<4>("v_min3_f32", simds, out, clk);
+    run<6>("s_and_b64", simds, out, clk);
+    run<7>("v_fma_f32 + s_and_b64 mix", simds, out, clk);
+    return 0;
+}
