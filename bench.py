@@ -52,6 +52,13 @@ def make_world(ctx, kind):
     raise ValueError(kind)
 
 
+# stream bytes of the other two stages of the per-batch kernel: shade reads the queue index, the ray
+# record, the hit and the primitive's shading data (4 + 48 + 8 + 20 B) and writes the next ray
+# (48 B); raygen writes a ray record (48 B)
+SHADE_BYTES_PER_RAY = 4.0 + 48.0 + 8.0 + 20.0 + 48.0
+RAYGEN_BYTES_PER_PATH = 48.0
+
+
 def trace_bytes_per_ray(n_box, n_tri, n_sph):
     """Algorithmic bytes the closest-hit kernel moves per ray: 32 B per box test (24 B box + 8 B
     links), 36 B per triangle test (three positions), 16 B per sphere test (centre + radius),
@@ -125,6 +132,8 @@ def main():
                     help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--staged", action="store_true",
+                    help="one launch per stage and depth (times the closest-hit kernel alone) instead of one kernel per batch")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even for one rank")
     ap.add_argument("--max-paths", type=int, default=0)
@@ -178,8 +187,9 @@ def main():
     n_tri = cst["tri_tests"] / cst["rays_traced"]
     n_sph = cst["sph_tests"] / cst["rays_traced"]
 
+    timed_flags = rt.RENDER_PROFILE | (rt.RENDER_STAGED if args.staged else 0)
     for _ in range(args.warmup):
-        step(rt.RENDER_PROFILE)
+        step(timed_flags)
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,12 +199,13 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    rays = 0
+    rays = paths = 0
     ms_trace = ms_shade = 0.0
     launches = 0
     for _ in range(args.steps):
-        st = step(rt.RENDER_PROFILE)
+        st = step(timed_flags)
         rays += st["rays_traced"]
+        paths += st["paths"]
         ms_trace += st["ms_trace"]
         ms_shade += st["ms_shade"]
         launches += st["trace_launches"]
@@ -214,8 +225,14 @@ def main():
         mean = accum.view(height, width, 3).mean().item() / spp
         value = total_rays / elapsed_max / 1e6
         bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph)
-        # rank 0's closest-hit kernel: algorithmic bytes of its launches / their summed duration
-        achieved = bytes_per_ray * rays / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
+        # rank 0's dominant kernel: algorithmic bytes of its launches / their summed duration.  Staged:
+        # the closest-hit kernel alone.  Default: the per-batch kernel, which also holds raygen and
+        # shade, so their stream bytes count too (shaded rays >= rays - paths: every ray either ends
+        # its path or is shaded).
+        algo_bytes = bytes_per_ray * rays
+        if not args.staged:
+            algo_bytes += SHADE_BYTES_PER_RAY * max(rays - paths, 0) + RAYGEN_BYTES_PER_PATH * paths
+        achieved = algo_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
         headline = args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size)
         out = {
             "metric": "Mrays/sec (whole node), Cornell box 1024^2 1k spp",
@@ -230,13 +247,14 @@ def main():
                        "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3),
                        "accum_sum": float(accum.double().sum().item())},
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace (closest hit)",
+                "bound": "hbm",
+                "kernel": "k_trace (closest hit)" if args.staged else "k_path (raygen + closest hit and shade per depth, one launch per batch)",
                 "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": measured_traffic() if headline else None,
+                "traffic": measured_traffic() if headline and not args.staged else None,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
-                "valu_issue_busy": measured_traffic("valu_issue_busy") if headline else None,
-                "algorithmic_bytes_per_launch": int(bytes_per_ray * rays / max(launches, 1)),
+                "valu_issue_busy": measured_traffic("valu_issue_busy") if headline and not args.staged else None,
+                "algorithmic_bytes_per_launch": int(algo_bytes / max(launches, 1)),
                 "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache; "
                          "the kernel is VALU-issue-bound, not HBM-bound (valu_issue_busy, profiles/r01_pmc_sq.txt)")
                         if achieved and achieved > HBM_PEAK_GBS else "",

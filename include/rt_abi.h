@@ -97,17 +97,22 @@ typedef struct {
     uint32_t band_rows, band_count, band_index;
     uint32_t reserved;
 } rt_render_params;
-#define RT_RENDER_PROFILE 1u       /* time every closest-hit launch with HIP events */
-#define RT_RENDER_COUNT_VISITS 2u  /* count box / triangle / sphere tests (slower) */
+#define RT_RENDER_PROFILE 1u       /* time the kernels that hold the closest hit with HIP events */
+#define RT_RENDER_COUNT_VISITS 2u  /* count box / triangle / sphere tests (slower; implies STAGED) */
+#define RT_RENDER_STAGED 4u        /* one launch per stage and depth (raygen, closest hit, shade) instead
+                                      of one kernel per batch that carries every segment of paths from
+                                      raygen to its last bounce; same image bit for bit, slower, but
+                                      the stages can be timed apart */
 
 typedef struct {
     uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */
     uint64_t paths;          /* camera samples */
     uint64_t box_tests, tri_tests, sph_tests;   /* with RT_RENDER_COUNT_VISITS */
-    uint64_t trace_launches; /* closest-hit kernel launches */
+    uint64_t trace_launches; /* launches of the kernel that holds the closest hit (one per batch, or
+                                one per batch and depth with RT_RENDER_STAGED) */
     double ms_render;        /* wall time of the call on the GPU stream */
-    double ms_trace;         /* with RT_RENDER_PROFILE: summed closest-hit kernel time */
-    double ms_shade;         /* with RT_RENDER_PROFILE: summed shade kernel time */
+    double ms_trace;         /* with RT_RENDER_PROFILE: summed time of those kernels */
+    double ms_shade;         /* with RT_RENDER_PROFILE and RT_RENDER_STAGED: summed shade kernel time */
 } rt_stats;
 
 /* ---- context: stands where ThreadPool::new() does (main.rs:443) ---------------------- */

@@ -29,7 +29,7 @@ MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
-RENDER_PROFILE, RENDER_COUNT_VISITS = 1, 2
+RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
 material_dt = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("param", "<f4"), ("flags", "<u4")])

@@ -427,6 +427,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
 
     const bool profile = (p->flags & RT_RENDER_PROFILE) != 0;
     const bool count = (p->flags & RT_RENDER_COUNT_VISITS) != 0;
+    const bool staged = count || (p->flags & RT_RENDER_STAGED) != 0 || std::getenv("RT_STAGED") != nullptr;
     const uint32_t rw = p->x1 - p->x0, rh = p->y1 - p->y0;
     const uint32_t tiles_x = (rw + 7) / 8, tiles_y_all = (rh + 7) / 8;
     const uint32_t band_count = p->band_count > 1 ? p->band_count : 1;
@@ -556,19 +557,27 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 return lr;
             };
             bind();
-            if (launch_raygen(cfg, *cam, g, p->seed, rb)) return fail(RT_ERR_DEVICE, "raygen launch failed");
-            for (uint32_t d = 0; d < p->max_bounces; d++) {
-                const bool last = d + 1 == p->max_bounces;
+            if (!staged) {
                 int lr = mark(0, [&]() {
-                    return launch_trace(cfg, s->dev, g, rb, d, last, p->t_min, p->sky_intensity, count);
+                    return launch_path(cfg, s->dev, *cam, g, p->seed, rb, p->max_bounces, p->t_min, p->sky_intensity);
                 });
-                if (lr) return fail(RT_ERR_DEVICE, "trace launch failed");
+                if (lr) return fail(RT_ERR_DEVICE, "path kernel launch failed");
                 trace_launches++;
-                if (last) break;
-                lr = mark(1, [&]() { return launch_shade(cfg, s->dev, g, rb, d); });
-                if (lr) return fail(RT_ERR_DEVICE, "shade launch failed");
-                cur ^= 1;
-                bind();
+            } else {
+                if (launch_raygen(cfg, *cam, g, p->seed, rb)) return fail(RT_ERR_DEVICE, "raygen launch failed");
+                for (uint32_t d = 0; d < p->max_bounces; d++) {
+                    const bool last = d + 1 == p->max_bounces;
+                    int lr = mark(0, [&]() {
+                        return launch_trace(cfg, s->dev, g, rb, d, last, p->t_min, p->sky_intensity, count);
+                    });
+                    if (lr) return fail(RT_ERR_DEVICE, "trace launch failed");
+                    trace_launches++;
+                    if (last) break;
+                    lr = mark(1, [&]() { return launch_shade(cfg, s->dev, g, rb, d); });
+                    if (lr) return fail(RT_ERR_DEVICE, "shade launch failed");
+                    cur ^= 1;
+                    bind();
+                }
             }
             // batches add to the same pixels: accumulate in batch order, across the streams
             if (last_pipe >= 0 && last_pipe != k)

@@ -598,12 +598,10 @@ __device__ __forceinline__ bool slot_pixel(const BatchGeom& g, uint32_t q, uint3
 // raygen: the per-sample head of the tile loop (main.rs:362-364) + Camera::get_ray
 // (camera.rs:80-89).  Wave s fills segment s with the camera rays of its path slots.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(RT_WAVE)
-k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
-         float4* __restrict__ B, float4* __restrict__ C, uint32_t* __restrict__ segcnt) {
-    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (seg >= g.n_seg) return;
-    const uint32_t base = seg * g.seg_len;
+// camera rays of segment `seg` into (A, B, C); returns how many there are
+__device__ __forceinline__ uint32_t raygen_segment(const rt_camera& cam, const BatchGeom& g, uint32_t seed_lo,
+                                                   uint32_t seed_hi, float4* __restrict__ A, float4* __restrict__ B,
+                                                   float4* __restrict__ C, uint32_t base, uint32_t lane) {
     const float inv_w = 1.0f / (float)(g.width - 1u);      // main.rs:330-331
     const float inv_h = 1.0f / (float)(g.height - 1u);
     uint32_t out = 0;
@@ -641,6 +639,15 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
         const uint32_t pos = base + wave_append(valid, out);
         if (valid) { A[pos] = a; B[pos] = b; C[pos] = c; }
     }
+    return out;
+}
+
+__global__ void __launch_bounds__(RT_WAVE)
+k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
+         float4* __restrict__ B, float4* __restrict__ C, uint32_t* __restrict__ segcnt) {
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
+    const uint32_t out = raygen_segment(cam, g, seed_lo, seed_hi, A, B, C, seg * g.seg_len, lane);
     if (lane == 0) segcnt[seg] = out;
 }
 
@@ -700,29 +707,21 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
 constexpr uint32_t STAMP_SLOTS = 32, STAMP_WAVES = 16384;
 __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 #endif
+// Closest hit for the n live rays of the segment at `base`: terminates paths (sky, emitter, depth
+// cap) or records the hit and queues the ray under its material kind; n0 / n1 / n2 return the
+// queue lengths.  Whole wave, converged.
 template <bool COUNT, int SWEEP>
-__global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
-k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
-        const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
-        uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf,
-        const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ qcnt, Totals* totals,
-        uint32_t last_depth, float t_min, float sky_intensity
-#ifdef RT_STAMPS
-        , uint32_t stamp_slot
-#endif
-        ) {
+__device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* __restrict__ A,
+                                              const float4* __restrict__ B, const float4* __restrict__ C,
+                                              uint2* __restrict__ hits, uint32_t* __restrict__ q0,
+                                              uint32_t* __restrict__ q1, uint32_t* __restrict__ q2,
+                                              float4* __restrict__ Lbuf, uint32_t base, uint32_t n, uint32_t lane,
+                                              uint32_t last_depth, float t_min, float sky_intensity, uint32_t& n0,
+                                              uint32_t& n1, uint32_t& n2, Counts& cnt) {
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
-    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (seg >= g.n_seg) return;
-#ifdef RT_STAMPS
-    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    const uint32_t base = seg * g.seg_len;
-    const uint32_t n = segcnt[seg];
     const float t_max = __builtin_inff();                  // main.rs:46: t_max = f32::INFINITY
-    uint32_t n0 = 0, n1 = 0, n2 = 0;
-    Counts cnt{0, 0, 0};
+    n0 = n1 = n2 = 0;
     auto enqueue = [&](uint32_t kind, uint32_t i) {
         uint32_t pos;
         pos = wave_append(kind == 0u, n0);
@@ -776,19 +775,49 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
             enqueue(kind, i);
         }
     }
+}
+
+#ifdef RT_STAMPS
+__device__ __forceinline__ void write_stamp(uint32_t stamp_slot, uint32_t seg, unsigned long long t0, uint32_t n) {
+    if (stamp_slot < STAMP_SLOTS && seg < STAMP_WAVES) {
+        unsigned long long* o = rt_stamps + ((size_t)stamp_slot * STAMP_WAVES + seg) * 4;
+        o[0] = t0;
+        o[1] = __builtin_amdgcn_s_memrealtime();
+        o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID, all 32 bits
+        o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | n;   // HW_REG_XCC_ID | rays
+    }
+}
+#define RT_STAMP_PARAM , uint32_t stamp_slot
+#define RT_STAMP_ARG , stamp_slot
+#else
+#define RT_STAMP_PARAM
+#define RT_STAMP_ARG
+#endif
+
+template <bool COUNT, int SWEEP>
+__global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
+k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
+        const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
+        uint32_t* __restrict__ q1, uint32_t* __restrict__ q2, float4* __restrict__ Lbuf,
+        const uint32_t* __restrict__ segcnt, uint32_t* __restrict__ qcnt, Totals* totals,
+        uint32_t last_depth, float t_min, float sky_intensity RT_STAMP_PARAM) {
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
+#ifdef RT_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t n = segcnt[seg];
+    uint32_t n0, n1, n2;
+    Counts cnt{0, 0, 0};
+    trace_segment<COUNT, SWEEP>(sc, A, B, C, hits, q0, q1, q2, Lbuf, seg * g.seg_len, n, lane, last_depth, t_min,
+                                sky_intensity, n0, n1, n2, cnt);
     if (lane == 0) {
         qcnt[seg] = n0;
         qcnt[g.n_seg + seg] = n1;
         qcnt[2u * g.n_seg + seg] = n2;
     }
 #ifdef RT_STAMPS
-    if (lane == 0 && stamp_slot < STAMP_SLOTS && seg < STAMP_WAVES) {
-        unsigned long long* o = rt_stamps + ((size_t)stamp_slot * STAMP_WAVES + seg) * 4;
-        o[0] = stamp_t0;
-        o[1] = __builtin_amdgcn_s_memrealtime();
-        o[2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID, all 32 bits
-        o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | n;   // HW_REG_XCC_ID | rays
-    }
+    if (lane == 0) write_stamp(stamp_slot, seg, stamp_t0, n);
 #endif
     if (COUNT) {
         atomicAdd(&totals->box, (unsigned long long)cnt.box);
@@ -893,6 +922,26 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
     }
 }
 
+// Material::scatter for the segment's three queues in turn; returns the number of surviving rays,
+// compacted to the front of the segment in (nA, nB, nC)
+__device__ __forceinline__ uint32_t shade_segment(const DevScene& sc, const float4* __restrict__ A,
+                                                  const float4* __restrict__ B, const float4* __restrict__ C,
+                                                  const uint2* __restrict__ hits, const uint32_t* __restrict__ q0,
+                                                  const uint32_t* __restrict__ q1, const uint32_t* __restrict__ q2,
+                                                  float4* __restrict__ nA, float4* __restrict__ nB,
+                                                  float4* __restrict__ nC, float4* __restrict__ Lbuf, uint32_t base,
+                                                  uint32_t n0, uint32_t n1, uint32_t n2, uint32_t depth, uint32_t lane) {
+    const uint32_t ctr = depth * 16u;
+    uint32_t out = 0;
+    if (sc.kinds_present & 1u)
+        shade_queue<RT_MAT_LAMBERT>(sc, A, B, C, hits, q0, nA, nB, nC, Lbuf, base, n0, ctr, lane, out);
+    if (sc.kinds_present & 2u)
+        shade_queue<RT_MAT_METAL>(sc, A, B, C, hits, q1, nA, nB, nC, Lbuf, base, n1, ctr, lane, out);
+    if (sc.kinds_present & 4u)
+        shade_queue<RT_MAT_DIELECTRIC>(sc, A, B, C, hits, q2, nA, nB, nC, Lbuf, base, n2, ctr, lane, out);
+    return out;
+}
+
 __global__ void __launch_bounds__(RT_WAVE)
 k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, const uint2* __restrict__ hits, const uint32_t* __restrict__ q0,
@@ -901,17 +950,65 @@ k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
         const uint32_t* __restrict__ qcnt, uint32_t* __restrict__ segcnt_next, uint32_t depth) {
     const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (seg >= g.n_seg) return;
-    const uint32_t base = seg * g.seg_len;
-    const uint32_t ctr = depth * 16u;
-    uint32_t out = 0;
-    if (sc.kinds_present & 1u)
-        shade_queue<RT_MAT_LAMBERT>(sc, A, B, C, hits, q0, nA, nB, nC, Lbuf, base, qcnt[seg], ctr, lane, out);
-    if (sc.kinds_present & 2u)
-        shade_queue<RT_MAT_METAL>(sc, A, B, C, hits, q1, nA, nB, nC, Lbuf, base, qcnt[g.n_seg + seg], ctr, lane, out);
-    if (sc.kinds_present & 4u)
-        shade_queue<RT_MAT_DIELECTRIC>(sc, A, B, C, hits, q2, nA, nB, nC, Lbuf, base, qcnt[2u * g.n_seg + seg], ctr,
-                                       lane, out);
+    const uint32_t out = shade_segment(sc, A, B, C, hits, q0, q1, q2, nA, nB, nC, Lbuf, seg * g.seg_len, qcnt[seg],
+                                       qcnt[g.n_seg + seg], qcnt[2u * g.n_seg + seg], depth, lane);
     if (lane == 0) segcnt_next[seg] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole life of a segment's paths in one kernel: raygen, then trace and shade per depth.  A
+// segment is touched by its own wave only, so nothing orders waves against each other: every
+// wave runs through the depths at its own pace and a wave slot is refilled the moment its wave
+// ends, instead of the chip draining at the end of every per-depth launch.  Between the stages
+// the wave's own stores must have been performed before it reads them back (other lanes wrote
+// what a lane reads): a workgroup-scope release + acquire fence, i.e. a wait for the stores.  The
+// CU's L1 is write-through and every access to a segment comes from the one CU its wave runs on,
+// so no cache has to be written back or invalidated (an agent-scope fence writes back and
+// invalidates L2 on this multi-die GPU: once per wave and stage that cost 2-4x the frame).
+// ---------------------------------------------------------------------------------------------
+struct PathBuffers {
+    float4 *A0, *B0, *C0, *A1, *B1, *C1;
+    uint2* hits;
+    uint32_t *q0, *q1, *q2;
+    float4* Lbuf;
+    uint32_t* segcnt;          // [max_bounces * n_seg]: live rays entering each depth (ray totals)
+};
+
+__device__ __forceinline__ void stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int SWEEP>
+__global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
+k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
+       uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
+    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (seg >= g.n_seg) return;
+#ifdef RT_STAMPS
+    const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t base = seg * g.seg_len;
+    uint32_t n = raygen_segment(cam, g, seed_lo, seed_hi, pb.A0, pb.B0, pb.C0, base, lane);
+    Counts cnt{0, 0, 0};
+    for (uint32_t d = 0; d < max_bounces; d++) {
+        if (lane == 0) pb.segcnt[d * g.n_seg + seg] = n;
+        if (n == 0) continue;                              // the remaining depths only record zero rays
+        const bool odd = (d & 1u) != 0;
+        float4* A = odd ? pb.A1 : pb.A0; float4* B = odd ? pb.B1 : pb.B0; float4* C = odd ? pb.C1 : pb.C0;
+        float4* nA = odd ? pb.A0 : pb.A1; float4* nB = odd ? pb.B0 : pb.B1; float4* nC = odd ? pb.C0 : pb.C1;
+        const bool last = d + 1u == max_bounces;
+        stage_fence();
+        uint32_t n0, n1, n2;
+        trace_segment<false, SWEEP>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
+                                    t_min, sky_intensity, n0, n1, n2, cnt);
+        if (last) break;
+        stage_fence();
+        n = shade_segment(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, nA, nB, nC, pb.Lbuf, base, n0, n1, n2, d, lane);
+    }
+#ifdef RT_STAMPS
+    if (lane == 0) write_stamp(stamp_slot, seg, stamp_t0, n);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1010,9 +1107,6 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
 #ifdef RT_STAMPS
     static uint32_t stamped_launches = 0;
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
-#define RT_STAMP_ARG , stamp_slot
-#else
-#define RT_STAMP_ARG
 #endif
     const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
     if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
@@ -1020,6 +1114,33 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
     else if (mode == 1) { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
 #undef RT_TRACE
+    return check_launch();
+}
+
+int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
+                const RenderBuffers& rb, uint32_t max_bounces, float t_min, float sky_intensity) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    PathBuffers pb;
+    pb.A0 = (float4*)rb.cur.A; pb.B0 = (float4*)rb.cur.B; pb.C0 = (float4*)rb.cur.C;
+    pb.A1 = (float4*)rb.next.A; pb.B1 = (float4*)rb.next.B; pb.C1 = (float4*)rb.next.C;
+    pb.hits = (uint2*)rb.hits;
+    pb.q0 = rb.queue[0]; pb.q1 = rb.queue[1]; pb.q2 = rb.queue[2];
+    pb.Lbuf = (float4*)rb.Lbuf;
+    pb.segcnt = rb.segcnt;
+    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+#ifdef RT_STAMPS
+    static uint32_t stamped = 0;
+    const uint32_t stamp_slot = stamped < STAMP_SLOTS ? stamped++ : 0xFFFFFFFFu;
+#endif
+#define RT_PATH(SWP)                                                                                    \
+    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
+                       (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
+    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
+    if (mode == 3) RT_PATH(3);
+    else if (mode == 2) RT_PATH(2);
+    else if (mode == 1) RT_PATH(1);
+    else RT_PATH(0);
+#undef RT_PATH
     return check_launch();
 }
 

@@ -152,6 +152,9 @@ int launch_raygen(const LaunchCfg&, const rt_camera&, const BatchGeom&, uint64_t
 int launch_trace(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
                  bool last_depth, float t_min, float sky_intensity, bool count);
 int launch_shade(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth);
+// raygen + (trace + shade) x max_bounces for every segment in one kernel
+int launch_path(const LaunchCfg&, const DevScene&, const rt_camera&, const BatchGeom&, uint64_t seed,
+                const RenderBuffers&, uint32_t max_bounces, float t_min, float sky_intensity);
 int launch_accumulate(const LaunchCfg&, const BatchGeom&, const RenderBuffers&, void* d_accum,
                       uint32_t max_bounces);
 int launch_tonemap(const LaunchCfg&, const void* d_accum, uint32_t spp, void* d_out, size_t npix);

@@ -189,3 +189,20 @@ def test_short_reciprocal_is_exact_on_this_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mismatches in range 0" in out.stdout
+
+
+def test_one_kernel_per_batch_equals_staged_launches(rt, ob, ctx):
+    """The default render runs one kernel per batch that carries every segment from raygen to the
+    last bounce; RENDER_STAGED launches the stages one by one.  Same rays, same order, same sums:
+    the frames must be bit-identical, for the sweep and for the per-lane walk, with several
+    batches in flight."""
+    for osc, size in ((ob.Scene.cornell_box(asset("cornell_box_plane.obj")), (72, 56)),
+                      (ob.Scene.world2(asset("thing.obj"), 1), (64, 48)), (ob.Scene.world1(), (64, 40))):
+        sc = mirror(rt, ctx, osc)
+        w, h = size
+        cam = product_camera(rt, osc, w, h)
+        fused, st = sc.render(cam, rt.Scene.params(w, h, 24, 6, osc.sky, max_paths=w * h * 5))
+        staged, st2 = sc.render(cam, rt.Scene.params(w, h, 24, 6, osc.sky, max_paths=w * h * 5, flags=rt.RENDER_STAGED))
+        assert st["rays_traced"] == st2["rays_traced"] and st["paths"] == st2["paths"]
+        assert st["trace_launches"] < st2["trace_launches"]
+        assert np.array_equal(fused.view(np.uint32), staged.view(np.uint32))
