@@ -328,6 +328,15 @@ int rt_scene_commit(rt_scene* s) {
         if (e != hipSuccess || bytes == 0) return e;
         return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     };
+    {   // the entries, then the TAG_END entry the wave sweep stops at
+        float end_entry[ENTRY_FLOATS] = {};
+        const uint32_t w = TAG_END << TAG_SHIFT;
+        std::memcpy(&end_entry[3], &w, 4);
+        HIP_TRY(s->d_entries.ensure(f.entries.size() * 4 + sizeof(end_entry)));
+        HIP_TRY(hipMemcpyAsync((char*)s->d_entries.p + f.entries.size() * 4, end_entry, sizeof(end_entry),
+                               hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));    // end_entry leaves scope
+    }
     HIP_TRY(upload(s->d_entries, f.entries.data(), f.entries.size() * 4));
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));

@@ -333,23 +333,25 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
     float bt0 = t_max, bt1 = t_max;
     uint32_t bp0 = RT_MISS, bp1 = RT_MISS;
     uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
-    // next entry at or after e that some lane stands on: a scalar scan that leaves the vector
-    // state alone; on0 / on1 = lanes whose ray 0 / ray 1 is at that entry
+    // Next entry at or after e that some lane stands on: a scalar scan that leaves the vector
+    // state alone; on0 / on1 = lanes whose ray 0 / ray 1 is at that entry.  The device array ends
+    // with a TAG_END entry at index n_ent, where finished (and absent) rays park their cursor, so
+    // the scan needs no bound and the walk is over when it fetches that entry.
     unsigned long long on0, on1;
     uint32_t e = 0;
     auto scan = [&]() {
         for (;;) {
             on0 = __ballot(cur0 == e);
             on1 = __ballot(cur1 == e);
-            if ((on0 | on1) != 0ull || e >= n_ent) break;
+            if ((on0 | on1) != 0ull) break;
             e++;
         }
     };
     scan();
+    f32x16 E = ent[e];                                 // one s_load_dwordx16
     // (the loop tests at the bottom, after the state update, so that the only values alive on the
     // back edge are the updated ones and they keep their registers)
-    if (e < n_ent) do {
-        const f32x16 E = ent[e];                       // one s_load_dwordx16
+    if ((f2u(E[3]) >> TAG_SHIFT) != TAG_END) do {
         const uint32_t w = f2u(E[3]);
         const uint32_t tag = w >> TAG_SHIFT;
         // What the entry does to a lane that is on it.  The state is written once, after the
@@ -443,7 +445,8 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
         select_into(cur1, nxt1, on1);
         e++;
         scan();
-    } while (e < n_ent);
+        E = ent[e];
+    } while ((f2u(E[3]) >> TAG_SHIFT) != TAG_END);
     h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1;
 }
 

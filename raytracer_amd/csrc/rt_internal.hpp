@@ -30,6 +30,7 @@ namespace rtamd {
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ENTRY_FLOATS = 16;
 constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
+constexpr uint32_t TAG_END = 3;   // device copy only: one entry behind the last, where the wave sweep stops
 constexpr uint32_t TAG_SHIFT = 30;
 constexpr uint32_t SKIP_MASK = (1u << TAG_SHIFT) - 1u;
 // Box entries, fourth float of the second float4 (unused by the reference-order walks): links for
