@@ -68,11 +68,11 @@ def trace_bytes_per_ray(n_box, n_tri, n_sph):
 
 
 def measured_traffic(key="hbm_bytes_per_launch"):
-    """HBM bytes per launch of the closest-hit kernel (or another figure) from the committed PMC
+    """HBM bytes per launch of the per-batch kernel (or another figure) from the committed PMC
     passes (rocprofv3 cannot run inside this process); None when the file is absent."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)["k_trace"][key]
+            return json.load(f)["k_path"][key]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -253,10 +253,11 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                 "traffic": measured_traffic() if headline and not args.staged else None,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
-                "valu_issue_busy": measured_traffic("valu_issue_busy") if headline and not args.staged else None,
+                "valu_pipe_busy": measured_traffic("valu_pipe_busy") if headline and not args.staged else None,
                 "algorithmic_bytes_per_launch": int(algo_bytes / max(launches, 1)),
-                "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache; "
-                         "the kernel is VALU-issue-bound, not HBM-bound (valu_issue_busy, profiles/r01_pmc_sq.txt)")
+                "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache, "
+                         "so most algorithmic bytes never reach HBM (traffic = what does); the kernel is bound by "
+                         "instruction issue, not by HBM (valu_pipe_busy, profiles/r01_pmc_sq.txt)")
                         if achieved and achieved > HBM_PEAK_GBS else "",
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "tests_per_ray": {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)},
