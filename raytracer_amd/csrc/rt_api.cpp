@@ -472,6 +472,12 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     const int n_pipes = (int)std::min<size_t>(n_batches, (size_t)ctx->n_pipes);
     if (n_pipes > 1) {
         max_paths = std::max<size_t>(64, max_paths / (size_t)n_pipes);
+        // A small job (one rank's share of a frame) is cut into at least 8 batches as long as a
+        // batch still fills the chip (8 Mi paths): the pipelines only overlap between batches, and
+        // the drain of the last batch is shorter when the batch is.
+        const size_t total = n_tiles * 64 * (size_t)n_samples;
+        if (!p->max_paths_in_flight)
+            max_paths = std::min(max_paths, std::max<size_t>((size_t)8 << 20, total / 8));
         tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
