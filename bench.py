@@ -178,6 +178,10 @@ def main():
         D.reduce_to_root(accum)
         return st
 
+    if grouped:
+        D.reduce_to_root(accum)                            # builds the communicator outside the timed region
+        torch.cuda.synchronize()
+
     # per-ray visit counts for the roofline: a counting pass over a few samples (not timed)
     cs = (samples[0], min(samples[1], samples[0] + 4))
     accum.zero_()
