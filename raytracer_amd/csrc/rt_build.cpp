@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <thread>
 
 #include "rt_internal.hpp"
 
@@ -77,9 +78,9 @@ struct Builder {
         e[4] = o.sphere.r;
         e[7] = u2f(o.prim_base);
     }
-    void push_triangle(uint32_t local) {
+    void write_triangle(size_t at, uint32_t local) {
         const rt_triangle& t = mesh->tris[local];
-        float* e = entry(push_entry());
+        float* e = entry(at);
         for (int k = 0; k < 3; k++) {
             e[k] = t.p[0][k];
             e[4 + k] = t.p[1][k] - t.p[0][k];  // v0v1, shape.rs:417
@@ -87,6 +88,12 @@ struct Builder {
         }
         e[3] = u2f(TAG_TRI << TAG_SHIFT);
         e[7] = u2f(mesh->prim_base + local);
+    }
+    void write_box(size_t at, const Box& b, size_t skip) {
+        float* e = entry(at);
+        e[0] = b.lo[0]; e[1] = b.lo[1]; e[2] = b.lo[2];
+        e[4] = b.hi[0]; e[5] = b.hi[1]; e[6] = b.hi[2];
+        e[3] = u2f((TAG_BOX << TAG_SHIFT) | (uint32_t)skip);
     }
 
     // compute_aabb (shape.rs:218-233): tight box of the triangles, then +-0.0001 on every face
@@ -101,26 +108,36 @@ struct Builder {
         return b;
     }
 
-    // Mesh::build_bvh (shape.rs:264-290) on idx[0..n), emitting in pre-order
-    void emit_mesh_range(uint32_t* idx, size_t n, int axis) {
+    // Mesh::build_bvh (shape.rs:264-290) on idx[0..n), written in pre-order at entries
+    // [at, at + 2n - 1): a subtree of n >= 1 triangles always takes 2n - 1 entries, so every
+    // node's place is known before its children are built and the two halves of a big node can
+    // be built by different threads (they sort disjoint index ranges and write disjoint entries).
+    static size_t mesh_entries(size_t n) { return n ? 2 * n - 1 : 0; }
+    void fill_mesh_range(uint32_t* idx, size_t n, int axis, size_t at, int fork_levels) {
         if (n == 0) return;                    // MeshBvhNode::None never hits
-        if (n == 1) { push_triangle(idx[0]); return; }
+        if (n == 1) { write_triangle(at, idx[0]); return; }
         if (n == 2) {
-            size_t b = push_box(padded_box(idx, 2));
-            push_triangle(idx[1]);             // left = pop() = last
-            push_triangle(idx[0]);             // right = pop() = first
-            close_box(b);
+            write_box(at, padded_box(idx, 2), at + 3);
+            write_triangle(at + 1, idx[1]);    // left = pop() = last
+            write_triangle(at + 2, idx[0]);    // right = pop() = first
             return;
         }
         const float* key = tri_min.data();
         std::stable_sort(idx, idx + n, [key, axis](uint32_t a, uint32_t b) {
             return key[a * 3 + axis] < key[b * 3 + axis];
         });
-        size_t bx = push_box(padded_box(idx, n));
-        size_t half = n / 2;                   // split_off(len / 2)
-        emit_mesh_range(idx, half, (axis + 1) % 3);
-        emit_mesh_range(idx + half, n - half, (axis + 1) % 3);
-        close_box(bx);
+        const size_t half = n / 2;             // split_off(len / 2)
+        const size_t left_at = at + 1, right_at = left_at + mesh_entries(half);
+        const int next = (axis + 1) % 3;
+        write_box(at, padded_box(idx, n), at + mesh_entries(n));   // before the halves get re-sorted
+        if (fork_levels > 0 && n >= 65536) {
+            std::thread left([=]() { fill_mesh_range(idx, half, next, left_at, fork_levels - 1); });
+            fill_mesh_range(idx + half, n - half, next, right_at, fork_levels - 1);
+            left.join();
+        } else {
+            fill_mesh_range(idx, half, next, left_at, 0);
+            fill_mesh_range(idx + half, n - half, next, right_at, 0);
+        }
     }
 
     void emit_object(uint32_t oi) {
@@ -137,8 +154,10 @@ struct Builder {
         }
         std::vector<uint32_t> idx(n);
         std::iota(idx.begin(), idx.end(), 0u);
-        out.entries.reserve(out.entries.size() + (2 * n + 1) * ENTRY_FLOATS);
-        emit_mesh_range(idx.data(), n, 0);     // Mesh::hit enters at the root node (shape.rs:455)
+        const size_t at = out.n_entries();
+        out.entries.resize(out.entries.size() + mesh_entries(n) * ENTRY_FLOATS, 0.0f);
+        // Mesh::hit enters at the root node (shape.rs:455); up to 2^5 threads on a big mesh
+        fill_mesh_range(idx.data(), n, 0, at, 5);
         mesh = nullptr;
     }
 
