@@ -56,6 +56,20 @@ __global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk
                               "v_fma_f32 %2, %2, %8, %8\n s_and_b64 %6, %6, %9\n v_fma_f32 %3, %3, %8, %8\n s_and_b64 %7, %7, %9"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : "v"(m), "s"(mask) : "scc");)
             mask ^= s0 ^ s1 ^ s2 ^ s3;
+        } else if (KIND == 8) {  // v_cmp -> SGPR mask -> v_cndmask that reads it (4 independent pairs)
+            REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %4\n v_cmp_lt_f32_e64 s[22:23], %1, %4\n v_cmp_lt_f32_e64 s[24:25], %2, %4\n v_cmp_lt_f32_e64 s[26:27], %3, %4\n"
+                              "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %1, %1, %4, s[22:23]\n v_cndmask_b32_e64 %2, %2, %4, s[24:25]\n v_cndmask_b32_e64 %3, %3, %4, s[26:27]"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");)
+        } else if (KIND == 9) {  // 8 v_fma_f32, then a compare + uniform branch that is never taken
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                              "s_cmp_eq_u32 %9, 0x12345\n s_cbranch_scc1 1f\n s_nop 0\n1:"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(i) : "scc");)
+        } else if (KIND == 10) { // v_cmp -> SGPR -> s_and (scalar ALU reads what the vector ALU wrote) -> v_cndmask
+            REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %4\n v_cmp_lt_f32_e64 s[22:23], %1, %4\n v_cmp_lt_f32_e64 s[24:25], %2, %4\n v_cmp_lt_f32_e64 s[26:27], %3, %4\n"
+                              "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n"
+                              "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[24:25]"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");)
         } else if (KIND == 5) {  // v_pk_mul_f32 with one scalar-register operand pair
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
@@ -85,7 +99,8 @@ static void run(const char* name, int simds, float* out, unsigned long long* clk
         double cyc = 0, real = 0;
         for (int b = 0; b < blocks; b++) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
         cyc /= blocks; real /= blocks;
-        const double n_inst = (double)ITERS * 64;
+        const double per_rep = KIND == 9 ? 10.0 : 8.0;    // instructions in one of the 8 repeats
+        const double n_inst = (double)ITERS * 8 * per_rep;
         printf("%-28s waves/SIMD %d: %.2f cycles per instruction per wave, %.2f SIMD cycles per instruction, clock %.2f GHz\n",
                name, w, cyc / n_inst, cyc / n_inst / w, cyc / real * 0.1);
     }
@@ -106,5 +121,8 @@ int main() {
     run<4>("v_min3_f32", simds, out, clk);
     run<6>("s_and_b64", simds, out, clk);
     run<7>("v_fma_f32 + s_and_b64 mix", simds, out, clk);
+    run<8>("v_cmp->sgpr->v_cndmask", simds, out, clk);
+    run<9>("8 v_fma + cmp + branch", simds, out, clk);
+    run<10>("v_cmp->s_and->v_cndmask", simds, out, clk);
     return 0;
 }
