@@ -179,11 +179,12 @@ int rt_context_create(int device_id, rt_context** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     ctx->grid_cap = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u;
-    // Segments (= waves) per batch.  Per-lane walk: two per wave slot of the chip (4 SIMDs x 8
-    // waves per CU); segments differ in how long their paths live and the surplus lets the
-    // dispatcher even that out.  Wave sweep: one per wave slot (its waves cost the same whatever
-    // their rays do).  Measured optima on the sphere / OBJ scenes and on the plane Cornell box.
-    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 64u;
+    // Segments (= waves) per batch.  Per-lane walk: 256 per CU, eight per wave slot of the chip
+    // (4 SIMDs x 8 waves per CU); segments differ a lot in how long their paths live, and the
+    // surplus lets the dispatcher even that out (10 M-triangle soup at depth 16: +75 % over two per
+    // slot; the sphere and OBJ scenes +0-10 %).  Wave sweep: one per wave slot (its cost per group
+    // of rays hardly depends on the rays, and short segments waste partly filled groups).
+    ctx->wave_target = (uint32_t)std::max(1, prop.multiProcessorCount) * 256u;
     ctx->wave_target_sweep = (uint32_t)std::max(1, prop.multiProcessorCount) * 32u;
     if (const char* e = std::getenv("RT_WAVE_TARGET")) {
         const long v = std::atol(e);
