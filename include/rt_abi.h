@@ -159,6 +159,11 @@ size_t rt_scene_num_prims(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
 /* host-only scenes: copies the flattened pre-order entry array (16 floats per entry) */
 int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
+/* host-only scenes: the same entries as the per-lane walks read them, in 32-byte units (8 floats):
+ * a box or a sphere is the first 8 floats of its entry in one unit, a triangle takes two units
+ * (floats 8-11 of its entry open the second); skip links count units */
+size_t rt_scene_num_units(const rt_scene* scene);
+int rt_scene_get_units(const rt_scene* scene, float* out, size_t n_floats);
 
 /* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */
 int rt_trace(rt_scene* scene, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out);

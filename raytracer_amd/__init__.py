@@ -91,6 +91,8 @@ def _load():
         "rt_scene_num_prims": (sz, [vp]),
         "rt_scene_num_entries": (sz, [vp]),
         "rt_scene_get_entries": (i32, [vp, vp, sz]),
+        "rt_scene_num_units": (sz, [vp]),
+        "rt_scene_get_units": (i32, [vp, vp, sz]),
         "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
         "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
         "rt_render": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
@@ -129,7 +131,8 @@ ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_context_stream",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_traversal", "rt_scene_commit",
-    "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_trace",
+    "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
+    "rt_scene_get_units", "rt_trace",
     "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
 HOST_SYMBOLS = [
@@ -267,6 +270,12 @@ class Scene:
         n = self.num_entries
         out = np.zeros((n, 16), dtype=np.float32)
         _check(lib.rt_scene_get_entries(self.h, _ptr(out), out.size))
+        return out
+
+    def units(self):
+        """The entries as the per-lane walks read them: (n_units, 8) floats."""
+        out = np.zeros((lib.rt_scene_num_units(self.h), 8), dtype=np.float32)
+        _check(lib.rt_scene_get_units(self.h, _ptr(out), out.size))
         return out
 
     def trace(self, rays, t_min=0.001, t_max=np.inf):

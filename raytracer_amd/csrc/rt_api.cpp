@@ -106,7 +106,7 @@ struct rt_scene {
     bool ordered_ok = false;
     bool committed = false;
     FlatScene flat;
-    DeviceBuffer d_entries, d_geo, d_meta, d_mats;
+    DeviceBuffer d_entries, d_units, d_geo, d_meta, d_mats;
     DevScene dev{};
 };
 
@@ -316,6 +316,7 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_entries = (uint32_t)s->flat.n_entries();
     s->dev.n_prims = (uint32_t)s->flat.n_prims();
     s->ordered_ok = s->flat.ordered_ok;
+    s->dev.n_units = (uint32_t)s->flat.n_units();
     s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
     if (!ctx) {                                // host-only scene: keep the flattened arrays
         s->committed = true;
@@ -339,11 +340,14 @@ int rt_scene_commit(rt_scene* s) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));    // end_entry leaves scope
     }
     HIP_TRY(upload(s->d_entries, f.entries.data(), f.entries.size() * 4));
+    HIP_TRY(upload(s->d_units, f.units.data(), f.units.size() * 4));
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
     HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     s->dev.entries = s->d_entries.p;
+    s->dev.units = s->d_units.p;
+    s->dev.n_units = (uint32_t)f.n_units();
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
     s->dev.materials = s->d_mats.p;
@@ -361,6 +365,7 @@ int rt_scene_commit(rt_scene* s) {
     // the host copies of the geometry are no longer needed
     for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
     s->flat.entries.clear(); s->flat.entries.shrink_to_fit();
+    s->flat.units.clear(); s->flat.units.shrink_to_fit();
     s->flat.prim_geo.clear(); s->flat.prim_geo.shrink_to_fit();
     s->committed = true;
     return RT_OK;
@@ -374,6 +379,16 @@ int rt_scene_get_entries(const rt_scene* s, float* out, size_t n_floats) {
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_entries needs a committed host-only scene");
     if (n_floats != s->flat.entries.size()) return fail(RT_ERR_INVALID, "rt_scene_get_entries: size mismatch");
     std::memcpy(out, s->flat.entries.data(), n_floats * sizeof(float));
+    return RT_OK;
+}
+
+size_t rt_scene_num_units(const rt_scene* s) { return s ? s->dev.n_units : 0; }
+
+int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_units: NULL argument");
+    if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_units needs a committed host-only scene");
+    if (n_floats != s->flat.units.size()) return fail(RT_ERR_INVALID, "rt_scene_get_units: size mismatch");
+    std::memcpy(out, s->flat.units.data(), n_floats * sizeof(float));
     return RT_OK;
 }
 

@@ -250,6 +250,36 @@ void annotate_children(FlatScene& out) {
     if (depth > ORDERED_MAX_DEPTH) out.ordered_ok = false;
 }
 
+// The compact form for the per-lane walks (FlatScene::units).
+void pack_units(FlatScene& out) {
+    const size_t n = out.n_entries();
+    auto word = [&](size_t i, int k) { uint32_t u; std::memcpy(&u, &out.entries[i * ENTRY_FLOATS + k], 4); return u; };
+    std::vector<uint32_t> unit_of(n + 1);
+    uint64_t u = 0;
+    for (size_t i = 0; i < n; i++) {
+        unit_of[i] = (uint32_t)u;
+        u += (word(i, 3) >> TAG_SHIFT) == TAG_TRI ? 2 : 1;
+    }
+    unit_of[n] = (uint32_t)u;
+    if (u > ORD_RIGHT_MASK) out.ordered_ok = false;
+    out.units.assign((size_t)u * 8, 0.0f);
+    for (size_t i = 0; i < n; i++) {
+        const float* e = &out.entries[i * ENTRY_FLOATS];
+        float* d = &out.units[(size_t)unit_of[i] * 8];
+        std::memcpy(d, e, 32);
+        const uint32_t tag = word(i, 3) >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            const uint32_t skip = (TAG_BOX << TAG_SHIFT) | unit_of[word(i, 3) & SKIP_MASK];
+            std::memcpy(&d[3], &skip, 4);
+            uint32_t link = word(i, 7);
+            if (link & ORD_RIGHT_MASK) link = (link & ~ORD_RIGHT_MASK) | (unit_of[link & ORD_RIGHT_MASK] & ORD_RIGHT_MASK);
+            std::memcpy(&d[7], &link, 4);
+        } else if (tag == TAG_TRI) {
+            std::memcpy(d + 8, e + 8, 16);     // v0v2 into the second unit
+        }
+    }
+}
+
 }  // namespace
 
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
@@ -321,6 +351,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     }
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
     annotate_children(out);
+    pack_units(out);
     return std::string();
 }
 

@@ -130,7 +130,10 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
 }
 
 // Per-lane walk of a whole wave (call converged; lanes without a ray pass valid = false).  Every
-// lane visits its own entries in the reference's order.  A lane that stands at a primitive waits
+// lane visits its own entries in the reference's order.  `ent` is the compact form of the entry
+// array: 32-byte units (two float4), a box or a sphere in one unit, a triangle in two (its v0v2
+// in the second); cursors and skip links count units.  A box visit therefore touches 32 bytes,
+// and a box and its first child usually share a 64-byte line.  A lane that stands at a primitive waits
 // there while boxes remain to be tested by other lanes, until prim_wait lanes stand at
 // primitives (or no lane stands at a box): the long primitive routines then run with many lanes
 // instead of once per loop trip for a few.
@@ -154,21 +157,22 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
             live = r.i < n_ent;
-            if (live) { a = ent[4 * r.i]; b = ent[4 * r.i + 1]; }
+            if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
-                    const float4 c = ent[4 * r.i + 2];
+                    const float4 c = ent[2 * r.i + 2];
                     tri_step(a, b, c, r, t_min);
+                    r.i = r.i + 2;             // a triangle takes two 32-byte units
                 } else {
                     if (COUNT) cnt.sph++;
                     sphere_step(a, b, r, t_min);
+                    r.i = r.i + 1;
                 }
-                r.i = r.i + 1;
                 live = r.i < n_ent;
-                if (live) { a = ent[4 * r.i]; b = ent[4 * r.i + 1]; }
+                if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
             }
         }
     }
@@ -212,9 +216,12 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
         else { sp--; r.i = stack[sp * 64u + lane]; }
         live = r.i < n_ent;
         if (live) {
-            a = ent[4 * r.i];
-            b = ent[4 * r.i + 1];
-            if (from_top) top = (f2u(a.w) >> TAG_SHIFT) == TAG_BOX ? (f2u(a.w) & SKIP_MASK) : r.i + 1;
+            a = ent[2 * r.i];
+            b = ent[2 * r.i + 1];
+            if (from_top) {
+                const uint32_t tg = f2u(a.w) >> TAG_SHIFT;
+                top = tg == TAG_BOX ? (f2u(a.w) & SKIP_MASK) : r.i + (tg == TAG_TRI ? 2u : 1u);
+            }
         }
     };
     if (valid) pop();
@@ -239,8 +246,8 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
                     next = first_is_near ? next : second;
                 }
                 r.i = next;
-                a = ent[4 * next];
-                b = ent[4 * next + 1];
+                a = ent[2 * next];
+                b = ent[2 * next + 1];
             } else {
                 pop();
             }
@@ -249,7 +256,7 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
             if (at_prim) {
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
-                    const float4 c = ent[4 * r.i + 2];
+                    const float4 c = ent[2 * r.i + 2];
                     tri_step(a, b, c, r, t_min);
                 } else {
                     if (COUNT) cnt.sph++;
@@ -523,11 +530,11 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             float t = t_max;
             uint32_t prim;
             if (SWEEP == 3)
-                closest_hit_ordered<COUNT>(ent, sc.n_entries, sc.prim_wait,
+                closest_hit_ordered<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait,
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, threadIdx.x & 63u,
                                            valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+                closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
@@ -767,11 +774,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             float t = t_max;
             uint32_t prim;
             if (SWEEP == 3)
-                closest_hit_ordered<COUNT>(ent, sc.n_entries, sc.prim_wait,
+                closest_hit_ordered<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait,
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, lane, valid, a.x,
                                            a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>(ent, sc.n_entries, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
                 kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);

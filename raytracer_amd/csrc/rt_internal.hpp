@@ -54,6 +54,11 @@ struct FlatScene {
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
     bool has_spheres = false;
+    // The same entries packed for the per-lane walks: 8 floats per 32-byte unit; a box or a sphere
+    // is its first two float4 in one unit, a triangle takes two units (the second holds v0v2);
+    // skip links and child links count units.
+    std::vector<float> units;
+    size_t n_units() const { return units.size() / 8; }
     uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
     bool ordered_ok = false;           // box entries carry the child links of the ordered walk
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
@@ -76,11 +81,13 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
 // Device side
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
-    const void* entries;      // float4[4 * n_entries]
+    const void* entries;      // float4[4 * n_entries] (+ the TAG_END entry): the wave sweep's form
+    const void* units;        // float4[2 * n_units]: the per-lane walks' form
     const void* prim_geo;     // float4[n_prims]
     const uint32_t* prim_meta;
     const void* materials;    // float4[2 * n_mats]
     uint32_t n_entries;
+    uint32_t n_units;
     uint32_t n_prims;
     uint32_t n_mats;
     uint32_t kinds_present;

@@ -341,3 +341,33 @@ def test_entry_layout_small_cases(rt, ob):
     assert [int(x >> 31) for x in u[[0, 2], 7]] == [1, 0]
     np.testing.assert_array_equal(ent[1, 4:7], [1, 0, 0])              # v0v1
     np.testing.assert_array_equal(ent[1, 8:11], [0, 1, 0])             # v0v2
+
+
+def test_units_are_the_entries_repacked(rt, ob):
+    """The per-lane walks read 32-byte units: boxes and spheres one unit, triangles two, links in
+    units.  Walking the units must give the entries back, with every link mapped."""
+    mats, objects, _ = random_scene(ob, 31, n_spheres=17, n_meshes=2, tris_per_mesh=23, extent=5.0)
+    sc = rt.Scene(None, mats, objects, 0)
+    ent, units = sc.entries(), sc.units()
+    eu, uu = ent.view(np.uint32), units.view(np.uint32)
+    unit_of, u = [], 0
+    for i in range(len(ent)):
+        unit_of.append(u)
+        u += 2 if (eu[i, 3] >> 30) == 1 else 1
+    unit_of.append(u)
+    assert u == len(units)
+    for i in range(len(ent)):
+        tag, k = int(eu[i, 3] >> 30), unit_of[i]
+        assert int(uu[k, 3] >> 30) == tag
+        np.testing.assert_array_equal(units[k, 0:3], ent[i, 0:3])
+        np.testing.assert_array_equal(units[k, 4:7], ent[i, 4:7])
+        if tag == 0:
+            assert int(uu[k, 3] & 0x3FFFFFFF) == unit_of[int(eu[i, 3] & 0x3FFFFFFF)]
+            second = int(eu[i, 7] & 0x1FFFFFFF)
+            assert int(uu[k, 7] & 0x1FFFFFFF) == (unit_of[second] if second else 0)
+            assert int(uu[k, 7] >> 29) == int(eu[i, 7] >> 29)
+        else:
+            assert uu[k, 7] == eu[i, 7]                                   # primitive id
+            if tag == 1:
+                np.testing.assert_array_equal(units[k + 1, 0:4], ent[i, 8:12])
+                assert not units[k + 1, 4:].any()
