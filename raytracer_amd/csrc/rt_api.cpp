@@ -79,6 +79,7 @@ struct rt_context {
     uint32_t wave_target = 8192, wave_target_sweep = 8192;
     int n_pipes = 2;
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // bracket a render call (rt_stats.ms_render)
     // The owner holds one reference and every scene created on the context another, so a scene
     // destroyed after rt_context_destroy() still finds its device and streams; work on a
     // destroyed context is refused.
@@ -94,6 +95,8 @@ struct rt_context {
             if (p.stream) (void)hipStreamDestroy(p.stream);
         }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
     }
 };
 
@@ -197,6 +200,8 @@ int rt_context_create(int device_id, rt_context** out) {
     }
     ctx->stream = ctx->pipes[0].stream;
     HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&ctx->ev_begin));
+    HIP_TRY(hipEventCreate(&ctx->ev_end));
     if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::min(MAX_PIPES, std::max(1, std::atoi(e)));
     *out = ctx.release();
     return RT_OK;
@@ -532,9 +537,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     };
 
     HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), st0));
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    HIP_TRY(hipEventCreate(&ev_begin));
-    HIP_TRY(hipEventCreate(&ev_end));
+    const hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
     HIP_TRY(hipEventRecord(ev_begin, st0));
     if (n_pipes > 1) {                         // the other streams start after whatever precedes the call
         HIP_TRY(hipEventRecord(ctx->ev_fork, st0));
@@ -647,9 +650,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         if (rc) return rc;
         stats->ms_trace = ms_by_kind[0];
         stats->ms_shade = ms_by_kind[1];
+    } else {
+        HIP_TRY(hipStreamSynchronize(st0));    // the call returns with the frame complete either way
     }
-    (void)hipEventDestroy(ev_begin);
-    (void)hipEventDestroy(ev_end);
 #ifdef RT_STAMPS
     { static bool dumped = false; if (!dumped && !count) { dumped = true; rtamd::dump_stamps(); } }
 #endif
