@@ -57,6 +57,29 @@ int rt_camera_setup(const float look_from[3], const float look_at[3], const floa
 int rt_world_render(rt_world* world, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
                     uint64_t seed, float* accum_rgb, rt_stats* stats);
 
+/* The progressive schedule of the tile job (main.rs:355-356, 409-411): cumulative sample counts
+ * min(10, spp), then doubling, capped at spp.  Writes up to `cap` of them and returns how many
+ * steps there are. */
+size_t rt_progressive_schedule(uint32_t spp, uint32_t* counts, size_t cap);
+
+/* One finished or in-progress block, as RenderEvent::BlockComplete(x, y, w, h, Vec<u32>) delivers
+ * it (main.rs:26-29, 399-407): 0x00RRGGBB pixels, row-major in the block.  Return non-zero to stop
+ * the render after the current step. */
+typedef int (*rt_block_fn)(void* user, uint32_t x, uint32_t y, uint32_t w, uint32_t h, const uint32_t* block_0rgb,
+                           uint32_t samples_done, uint32_t samples_total);
+
+/* render() with its live updates: the frame is rendered in the schedule's steps; after each, every
+ * 64 x 64 block (main.rs:22; edge blocks clipped, main.rs:337-346) is tonemapped with the samples
+ * so far (main.rs:369-373), gets the red corner marks of an unfinished block while more samples
+ * are to come (main.rs:377-396), and is handed to `on_block` in the reference's j-then-i order.
+ * accum_rgb (host, width*height*3, may be NULL) receives the final linear sums. */
+int rt_world_render_progressive(rt_world* world, uint32_t width, uint32_t height, uint32_t spp,
+                                uint32_t max_bounces, uint64_t seed, rt_block_fn on_block, void* user,
+                                float* accum_rgb, rt_stats* stats);
+
+/* binary PPM (P6) of a 0x00RRGGBB frame */
+int rt_write_ppm(const char* path, const uint32_t* pixels_0rgb, uint32_t width, uint32_t height);
+
 /* OBJ ingest (Mesh::from_file, shape.rs:347-406): number of triangles / models / faces */
 int rt_obj_count(const char* path, size_t* n_tris, size_t* n_models, size_t* n_faces);
 

@@ -66,6 +66,11 @@ class RtError(RuntimeError):
     pass
 
 
+# rt_block_fn: (user, x, y, w, h, block_0rgb, samples_done, samples_total) -> int
+BLOCK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                       C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -118,6 +123,9 @@ def _load():
         "rt_camera_setup": (i32, [vp, vp, vp, f32, f32, f32, f32, vp]),
         "rt_world_render": (i32, [vp, u32, u32, u32, u32, C.c_uint64, vp, C.POINTER(Stats)]),
         "rt_obj_count": (i32, [C.c_char_p, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+        "rt_progressive_schedule": (sz, [u32, vp, sz]),
+        "rt_world_render_progressive": (i32, [vp, u32, u32, u32, u32, C.c_uint64, BLOCK_FN, vp, vp, C.POINTER(Stats)]),
+        "rt_write_ppm": (i32, [C.c_char_p, vp, u32, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -140,7 +148,8 @@ HOST_SYMBOLS = [
     "rt_world_create_soup", "rt_world_destroy", "rt_world_scene", "rt_world_sky_intensity",
     "rt_world_camera", "rt_world_num_materials", "rt_world_get_materials", "rt_world_num_objects",
     "rt_world_object_info", "rt_world_get_sphere", "rt_world_get_mesh", "rt_world_root_kind",
-    "rt_camera_setup", "rt_world_render", "rt_obj_count",
+    "rt_camera_setup", "rt_world_render", "rt_obj_count", "rt_progressive_schedule",
+    "rt_world_render_progressive", "rt_write_ppm",
 ]
 
 
@@ -405,12 +414,43 @@ class World:
     def params(self, width, height, spp, max_bounces, **kw):
         return Scene.params(width, height, spp, max_bounces, self.sky, **kw)
 
+    def render_progressive(self, width, height, spp, max_bounces, on_block=None, seed=DEFAULT_SEED):
+        """render() with its live updates: on_block(x, y, w, h, block[h,w] uint32, done, total) after
+        every step of the progressive schedule for every 64x64 block (return True to stop).
+        Returns (sums[H,W,3], stats)."""
+        acc = np.zeros((height, width, 3), dtype=np.float32)
+        st = Stats()
+
+        def thunk(_user, x, y, w, h, ptr, done, total):
+            if on_block is None:
+                return 0
+            blk = np.ctypeslib.as_array(ptr, shape=(h, w)).copy()
+            return 1 if on_block(x, y, w, h, blk, done, total) else 0
+
+        cb = BLOCK_FN(thunk)
+        _check(lib.rt_world_render_progressive(self.h, width, height, spp, max_bounces, seed, cb, None, _ptr(acc),
+                                               C.byref(st)))
+        return acc, st.as_dict()
+
     def render(self, width, height, spp, max_bounces, seed=DEFAULT_SEED):
         """render() drop-in: full frame, samples [0, spp); returns (sums[H,W,3], stats)."""
         acc = np.zeros((height, width, 3), dtype=np.float32)
         st = Stats()
         _check(lib.rt_world_render(self.h, width, height, spp, max_bounces, seed, _ptr(acc), C.byref(st)))
         return acc, st.as_dict()
+
+
+def progressive_schedule(spp):
+    """Cumulative sample counts of the reference's progressive tile job (main.rs:355-356, 409-411)."""
+    n = lib.rt_progressive_schedule(spp, None, 0)
+    out = np.zeros(n, dtype=np.uint32)
+    lib.rt_progressive_schedule(spp, _ptr(out), n)
+    return [int(v) for v in out]
+
+
+def write_ppm(path, pixels_0rgb):
+    px = np.ascontiguousarray(pixels_0rgb, dtype=np.uint32)
+    _check(lib.rt_write_ppm(str(path).encode(), _ptr(px), px.shape[1], px.shape[0]))
 
 
 def camera_setup(look_from, look_at, vup, vfov, aperture, focus_dist, aspect_ratio):

@@ -2,9 +2,11 @@
 
 #include "rt_host.h"
 
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <string>
+#include <vector>
 
 #include "scene_api.hpp"
 
@@ -113,6 +115,38 @@ int rt_world_render(rt_world* w, uint32_t width, uint32_t height, uint32_t spp, 
     if (!w || !accum_rgb) return host_fail("rt_world_render: NULL argument");
     if (spp == 0) return host_fail("rt_world_render: spp must be positive");
     return w->renderer->render(width, height, spp, max_bounces, seed, accum_rgb, stats);
+}
+
+size_t rt_progressive_schedule(uint32_t spp, uint32_t* counts, size_t cap) {
+    const std::vector<uint32_t> s = progressive_schedule(spp);
+    for (size_t i = 0; i < s.size() && i < cap && counts; i++) counts[i] = s[i];
+    return s.size();
+}
+
+int rt_world_render_progressive(rt_world* w, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
+                                uint64_t seed, rt_block_fn on_block, void* user, float* accum_rgb, rt_stats* stats) {
+    if (!w) return host_fail("rt_world_render_progressive: NULL world");
+    if (spp == 0) return host_fail("rt_world_render_progressive: spp must be positive");
+    if (width < 2 || height < 2) return host_fail("rt_world_render_progressive: width and height must be at least 2");
+    return w->renderer->render_progressive(width, height, spp, max_bounces, seed, on_block, user, accum_rgb, stats);
+}
+
+int rt_write_ppm(const char* path, const uint32_t* px, uint32_t width, uint32_t height) {
+    if (!path || !px) return host_fail("rt_write_ppm: NULL argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return host_fail(std::string("rt_write_ppm: cannot open ") + path);
+    std::fprintf(f, "P6\n%u %u\n255\n", width, height);
+    std::vector<unsigned char> row((size_t)width * 3);
+    bool ok = true;
+    for (uint32_t y = 0; y < height && ok; y++) {
+        for (uint32_t x = 0; x < width; x++) {
+            const uint32_t c = px[(size_t)y * width + x];
+            row[x * 3] = (unsigned char)(c >> 16); row[x * 3 + 1] = (unsigned char)(c >> 8); row[x * 3 + 2] = (unsigned char)c;
+        }
+        ok = std::fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    ok = std::fclose(f) == 0 && ok;
+    return ok ? RT_OK : host_fail(std::string("rt_write_ppm: write failed: ") + path);
 }
 
 int rt_obj_count(const char* path, size_t* n_tris, size_t* n_models, size_t* n_faces) {

@@ -298,7 +298,7 @@ SceneDescription describe(const World& world) {
 }
 
 // ---- GpuRenderer ----------------------------------------------------------------------------
-GpuRenderer::GpuRenderer(rt_context* ctx, World world) : world_(std::move(world)) {
+GpuRenderer::GpuRenderer(rt_context* ctx, World world) : ctx_(ctx), world_(std::move(world)) {
     desc_ = describe(world_);
     auto ok = [](int rc) { if (rc != RT_OK) throw std::runtime_error(rt_last_error()); };
     ok(rt_scene_create(ctx, &scene_));
@@ -344,6 +344,80 @@ int GpuRenderer::render(uint32_t width, uint32_t height, uint32_t spp, uint32_t 
     p.sky_intensity = world_.sky_intensity;
     p.seed = seed;
     return rt_render(scene_, &c, &p, accum_rgb, stats);
+}
+
+// main.rs:355-356, 409-411
+std::vector<uint32_t> progressive_schedule(uint32_t spp) {
+    std::vector<uint32_t> counts;
+    if (spp == 0) return counts;
+    uint32_t next = std::min<uint32_t>(10u, spp);
+    for (;;) {
+        counts.push_back(next);
+        if (next >= spp) break;
+        next = (uint32_t)std::min<uint64_t>((uint64_t)next * 2u, spp);
+    }
+    return counts;
+}
+
+int GpuRenderer::render_progressive(uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
+                                    uint64_t seed, rt_block_fn on_block, void* user, float* accum_rgb,
+                                    rt_stats* stats) {
+    constexpr uint32_t BLOCK = 64;             // BLOCK_SIZE, main.rs:22
+    Camera cam = world_.camera;
+    cam.setup((float)width / (float)height);   // main.rs:324-325
+    const rt_camera c = cam.describe();
+    rt_render_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.width = width; p.height = height;
+    p.x0 = 0; p.y0 = 0; p.x1 = width; p.y1 = height;
+    p.max_bounces = max_bounces;
+    p.t_min = 0.001f;                          // main.rs:46
+    p.sky_intensity = world_.sky_intensity;
+    p.seed = seed;
+    const size_t npix = (size_t)width * height;
+    std::vector<float> accum(npix * 3, 0.0f);
+    std::vector<uint32_t> frame(npix), block;
+    rt_stats total;
+    std::memset(&total, 0, sizeof(total));
+    uint32_t done = 0;
+    bool stop = false;
+    for (uint32_t upto : progressive_schedule(spp)) {
+        p.sample_begin = done; p.sample_end = upto;
+        rt_stats st;
+        int rc = rt_render(scene_, &c, &p, accum.data(), &st);
+        if (rc) return rc;
+        total.rays_traced += st.rays_traced; total.paths += st.paths;
+        total.trace_launches += st.trace_launches; total.ms_render += st.ms_render;
+        total.ms_trace += st.ms_trace; total.ms_shade += st.ms_shade;
+        done = upto;
+        rc = rt_tonemap(ctx_, accum.data(), done, frame.data(), npix);    // main.rs:369-373
+        if (rc) return rc;
+        if (on_block) {
+            const bool unfinished = done < spp;
+            for (uint32_t by = 0; by < height; by += BLOCK)
+                for (uint32_t bx = 0; bx < width; bx += BLOCK) {
+                    const uint32_t bw = std::min(BLOCK, width - bx), bh = std::min(BLOCK, height - by);
+                    block.resize((size_t)bw * bh);
+                    for (uint32_t y = 0; y < bh; y++)
+                        std::memcpy(&block[(size_t)y * bw], &frame[(size_t)(by + y) * width + bx], bw * 4u);
+                    if (unfinished) {          // main.rs:377-396: red marks in the corners
+                        const uint32_t red = 0x00FF0000u;
+                        auto set = [&](uint32_t x, uint32_t y) { block[(size_t)y * bw + x] = red; };
+                        for (uint32_t x = 0; x < std::min(5u, bw); x++) {
+                            set(x, 0); set(x, bh - 1); set(bw - x - 1, 0); set(bw - x - 1, bh - 1);
+                        }
+                        for (uint32_t y = 0; y < std::min(5u, bh); y++) {
+                            set(0, y); set(bw - 1, y); set(0, bh - y - 1); set(bw - 1, bh - y - 1);
+                        }
+                    }
+                    if (on_block(user, bx, by, bw, bh, block.data(), done, spp) != 0) stop = true;
+                }
+        }
+        if (stop) break;
+    }
+    if (accum_rgb) std::memcpy(accum_rgb, accum.data(), accum.size() * sizeof(float));
+    if (stats) *stats = total;
+    return RT_OK;
 }
 
 }  // namespace rthost

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "rt_abi.h"
+#include "rt_host.h"
 
 namespace rthost {
 
@@ -175,11 +176,17 @@ public:
     // all pixels, samples [0, spp); adds linear sums into accum_rgb (host memory)
     int render(uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces, uint64_t seed,
                float* accum_rgb, rt_stats* stats);
+    // the same frame in the reference's progressive steps, every 64 x 64 block delivered after each
+    int render_progressive(uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces, uint64_t seed,
+                           rt_block_fn on_block, void* user, float* accum_rgb, rt_stats* stats);
 private:
+    rt_context* ctx_ = nullptr;
     World world_;
     SceneDescription desc_;
     rt_scene* scene_ = nullptr;
 };
+
+std::vector<uint32_t> progressive_schedule(uint32_t spp);
 
 // OBJ ingest shared by Mesh::from_file and rt_obj_count
 struct ObjModel { std::string name; int material_id = -1; std::vector<uint32_t> vi, ni; };

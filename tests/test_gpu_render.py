@@ -206,3 +206,36 @@ def test_one_kernel_per_batch_equals_staged_launches(rt, ob, ctx):
         assert st["rays_traced"] == st2["rays_traced"] and st["paths"] == st2["paths"]
         assert st["trace_launches"] < st2["trace_launches"]
         assert np.array_equal(fused.view(np.uint32), staged.view(np.uint32))
+
+
+def test_progressive_render_delivers_the_reference_block_events(rt, ob, ctx):
+    """rt_world_render_progressive: steps 10, 20, 40, 50 of a 50-spp frame; after each, every 64x64
+    block (edge blocks clipped) in j-then-i order, tonemapped with the samples so far, with red
+    corner marks while unfinished (main.rs:355-411).  The final sums equal a one-call render up to
+    f32 summation grouping."""
+    wld = rt.World.cornell_box(ctx, asset("cornell_box_plane.obj"))
+    w, h, spp = 150, 100, 50                               # 3 x 2 blocks, clipped on both edges
+    events = []
+    acc, st = wld.render_progressive(w, h, spp, 6, lambda *e: events.append(e) and False)
+    assert st["paths"] == w * h * spp
+    steps = rt.progressive_schedule(spp)
+    blocks = [(x, y, min(64, w - x), min(64, h - y)) for y in range(0, h, 64) for x in range(0, w, 64)]
+    assert [(e[0], e[1], e[2], e[3], e[5]) for e in events] == [b + (s,) for s in steps for b in blocks]
+    assert all(e[6] == spp for e in events)
+    final = ctx.tonemap(acc, spp).reshape(h, w)
+    red = 0x00FF0000
+    for x, y, bw, bh, blk, done, _ in events:
+        assert blk.shape == (bh, bw)
+        corners = blk[0, 0] == red and blk[bh - 1, bw - 1] == red and blk[0, bw - 1] == red and blk[bh - 1, 0] == red
+        if done < spp:
+            assert corners and (blk[0, :5] == red).all() and (blk[:5, 0] == red).all()
+            assert (blk[1:-1, 1:-1] != red).any()
+        else:
+            assert np.array_equal(blk, final[y:y + bh, x:x + bw])
+    one, st1 = wld.render(w, h, spp, 6)
+    assert st1["rays_traced"] == st["rays_traced"]
+    np.testing.assert_allclose(acc, one, rtol=2e-5, atol=1e-6)
+    # a callback that returns True stops after the step it is in
+    seen = []
+    wld.render_progressive(w, h, spp, 6, lambda *e: seen.append(e[5]) or True)
+    assert set(seen) == {10} and len(seen) == len(blocks)

@@ -371,3 +371,20 @@ def test_units_are_the_entries_repacked(rt, ob):
             if tag == 1:
                 np.testing.assert_array_equal(units[k + 1, 0:4], ent[i, 8:12])
                 assert not units[k + 1, 4:].any()
+
+
+def test_progressive_schedule_and_ppm(rt, tmp_path):
+    """main.rs:355-356, 409-411: min(10, spp), then doubling, capped at spp."""
+    assert rt.progressive_schedule(1) == [1]
+    assert rt.progressive_schedule(10) == [10]
+    assert rt.progressive_schedule(11) == [10, 11]
+    assert rt.progressive_schedule(50) == [10, 20, 40, 50]
+    assert rt.progressive_schedule(1024) == [10, 20, 40, 80, 160, 320, 640, 1024]
+    px = np.array([[0x00FF0000, 0x0000FF00, 0x000000FF], [0x00102030, 0, 0x00FFFFFF]], dtype=np.uint32)
+    path = tmp_path / "f.ppm"
+    rt.write_ppm(path, px)
+    raw = path.read_bytes()
+    assert raw.startswith(b"P6\n3 2\n255\n")
+    assert raw[len(b"P6\n3 2\n255\n"):] == bytes([255, 0, 0, 0, 255, 0, 0, 0, 255, 0x10, 0x20, 0x30, 0, 0, 0, 255, 255, 255])
+    with pytest.raises(rt.RtError):
+        rt.write_ppm(tmp_path / "no_such_dir" / "f.ppm", px)
