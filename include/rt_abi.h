@@ -179,9 +179,9 @@ int rt_trace_device(rt_scene* scene, const void* d_rays, size_t n, float t_min, 
  * count (or calls rt_tonemap) afterwards. */
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
               float* accum_rgb, rt_stats* stats);
-/* same, accumulating into a device buffer; returns after the work is queued and stats (if
- * not NULL) forces a synchronise.  This is the call a multi-GPU job makes on every rank
- * before it sum-reduces the buffers to rank 0. */
+/* same, accumulating into a device buffer; returns when the frame part is complete in that
+ * buffer.  This is the call a multi-GPU job makes on every rank before it sum-reduces the
+ * buffers to rank 0. */
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
                      void* d_accum_rgb, rt_stats* stats);
 
