@@ -239,3 +239,22 @@ def test_progressive_render_delivers_the_reference_block_events(rt, ob, ctx):
     seen = []
     wld.render_progressive(w, h, spp, 6, lambda *e: seen.append(e[5]) or True)
     assert set(seen) == {10} and len(seen) == len(blocks)
+
+
+def test_depth_extremes(rt, ob, ctx):
+    """max_bounces = 1: one closest-hit query per path and only emitted / sky radiance survives
+    (main.rs:41-43 returns black for the next bounce); max_bounces = 64 (the limit): paths run
+    until they leave or are absorbed, ray counts agree with the oracle's."""
+    osc = ob.Scene.world1()
+    sc = mirror(rt, ctx, osc)
+    cam = product_camera(rt, osc, 64, 48)
+    g, st = sc.render(cam, rt.Scene.params(64, 48, 16, 1, osc.sky))
+    assert st["rays_traced"] == st["paths"] == 64 * 48 * 16
+    a, _, st_a = osc.render(64, 48, 16, 1)
+    assert st_a["rays"] == st_a["paths"]
+    assert abs(g.mean() - a.mean()) <= 0.05 * a.mean() + 1e-6
+    _compare(rt, ob, ctx, ob.Scene.cornell_box(asset("cornell_box_plane.obj")), 96, 96, 64, 64, clip=4.0)
+    with pytest.raises(rt.RtError):
+        sc.render(cam, rt.Scene.params(64, 48, 1, 65, osc.sky))
+    with pytest.raises(rt.RtError):
+        sc.render(cam, rt.Scene.params(64, 48, 1, 0, osc.sky))
