@@ -86,13 +86,41 @@ def random_rays(ob, seed, n, lo, hi, toward=None):
     return rays
 
 
+def adversarial_rays(rt, seed, n, extent):
+    """Rays that stress the comparison forms of the box and primitive tests: a zero or negative-zero
+    direction component, axis-aligned directions, origins on integer planes, tiny and huge
+    directions."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, dtype=rt.ray_dt)
+    o = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = rng.integers(0, 6, n)
+    axis = rng.integers(0, 3, n)
+    idx = np.arange(n)
+    d[idx[k == 0], axis[k == 0]] = 0.0
+    d[idx[k == 1], axis[k == 1]] = -0.0
+    m = k == 2
+    d[m] = 0.0
+    d[idx[m], axis[m]] = rng.choice([-1.0, 1.0], m.sum())
+    o[k == 3] = np.round(o[k == 3])
+    d[k == 4] *= np.float32(1e-20)
+    d[k == 5] *= np.float32(1e18)
+    rays["o"], rays["d"] = o, d
+    return rays
+
+
 def assert_hits_equal(got, want, t_rtol=0.0):
-    """prim id exact; t bit-exact by default (t_rtol=0) or within t_rtol relative."""
+    """prim id exact; t bit-exact by default (t_rtol=0) or within t_rtol relative.  A NaN t (the
+    reference accepts a sphere hit whose discriminant overflowed to NaN, shape.rs:25-36) must be a
+    NaN on both sides; its sign and payload are the hardware's default NaN and are not compared."""
     assert got.shape == want.shape
     bad = np.nonzero(got["prim_id"] != want["prim_id"])[0]
     assert bad.size == 0, f"{bad.size} prim id mismatches, first at ray {bad[:5]}: " \
                           f"{got['prim_id'][bad[:5]]} vs {want['prim_id'][bad[:5]]}"
     hit = want["prim_id"] != 0xFFFFFFFF
+    nan = np.isnan(want["t"])
+    assert np.array_equal(np.isnan(got["t"][hit]), nan[hit])
+    hit = hit & ~nan
     if t_rtol == 0.0:
         tb = np.nonzero(got["t"][hit].view(np.uint32) != want["t"][hit].view(np.uint32))[0]
         assert tb.size == 0, f"{tb.size} t values differ in bits"
@@ -101,5 +129,6 @@ def assert_hits_equal(got, want, t_rtol=0.0):
         assert rel.max(initial=0.0) <= t_rtol
     assert np.array_equal(got["front_face"][hit], want["front_face"][hit])
     assert np.array_equal(got["mat"][hit], want["mat"][hit])
-    np.testing.assert_allclose(got["p"][hit], want["p"][hit], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(got["n"][hit], want["n"][hit], rtol=1e-6, atol=1e-6)
+    fin = hit & np.isfinite(want["p"]).all(axis=-1) & np.isfinite(want["n"]).all(axis=-1)
+    np.testing.assert_allclose(got["p"][fin], want["p"][fin], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got["n"][fin], want["n"][fin], rtol=1e-6, atol=1e-6)

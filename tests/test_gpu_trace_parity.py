@@ -4,7 +4,7 @@ identical topology, boxes and arithmetic make it exact, so the tests demand exac
 import numpy as np
 import pytest
 
-from helpers import asset, assert_hits_equal, mirror, random_rays, random_scene
+from helpers import adversarial_rays, asset, assert_hits_equal, mirror, random_rays, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -153,3 +153,23 @@ def test_context_destroyed_before_its_scene(rt, ob):
     with pytest.raises(rt.RtError):
         sc.trace(rays)
     sc.close()
+
+
+@pytest.mark.parametrize("root", [0, 2])
+def test_adversarial_rays(rt, ob, ctx, root):
+    """Zero and negative-zero direction components (inv_d = +-inf, NaN slabs: math.rs:152-162),
+    axis-aligned rays, origins on integer planes, directions of magnitude 1e-20 and 1e18 (denormal
+    and overflowing intermediates; a NaN discriminant is accepted as a hit, shape.rs:25-36)."""
+    mats, objects, _ = random_scene(ob, 7 + root, n_spheres=45, n_meshes=2, tris_per_mesh=120)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(ctx, mats, objects, root)
+    rays = adversarial_rays(rt, 5 + root, 120000, 12.0)
+    want, _ = osc.trace(rays)
+    assert np.isnan(want["t"]).any() or root == 0
+    _check_all_modes(rt, sc, rays, want)
+    osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    sc = mirror(rt, ctx, osc)
+    rays = adversarial_rays(rt, 9, 120000, 560.0)
+    rays["o"] = np.abs(rays["o"]) * np.float32([-1.0, -1.0, 1.0])          # inside the room
+    want, _ = osc.trace(rays)
+    _check_all_modes(rt, sc, rays, want)

@@ -1,0 +1,48 @@
+"""Ad-hoc parity campaign: random scenes x random and adversarial rays, every traversal form against
+the oracle (primitive id exact, t bit-exact).  Run on a GPU box: python tools/fuzz_parity.py [seeds]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import raytracer_amd as rt                      # noqa: E402
+from oracle import binding as ob                # noqa: E402
+from helpers import adversarial_rays, random_rays, random_scene   # noqa: E402
+
+
+def main():
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    ctx = rt.Context(0)
+    bad = 0
+    for seed in range(1, n_seeds + 1):
+        rng = np.random.default_rng(seed)
+        root = [0, 2][seed % 2]
+        mats, objects, _ = random_scene(ob, seed, n_spheres=int(rng.integers(0, 80)), n_meshes=int(rng.integers(0, 4)),
+                                        tris_per_mesh=int(rng.integers(1, 400)))
+        osc = ob.Scene.from_description(mats, objects, root)
+        sc = rt.Scene(ctx, mats, objects, root)
+        batches = [("random", random_rays(ob, seed + 100, 200000, -12.0, 12.0)), ("adversarial", adversarial_rays(rt, seed, 100000, 12.0))]
+        for name, rays in batches:
+            want, _ = osc.trace(rays)
+            for mode, label in ((rt.TRAVERSAL_PER_LANE, "per-lane"), (rt.TRAVERSAL_SWEEP, "sweep")):
+                sc.set_traversal(mode)
+                n = len(rays) if sc.num_entries <= 600 or mode == rt.TRAVERSAL_PER_LANE else 30000
+                got = sc.trace(rays[:n])
+                w = want[:n]
+                hit = (w["prim_id"] != rt.MISS) & ~(np.isnan(w["t"]) & np.isnan(got["t"]))   # NaN payloads differ by hardware
+                m_prim = int((got["prim_id"] != w["prim_id"]).sum())
+                m_t = int((got["t"][hit].view(np.uint32) != w["t"][hit].view(np.uint32)).sum())
+                if m_prim or m_t:
+                    bad += 1
+                    k = np.nonzero(got["prim_id"] != w["prim_id"])[0][:3]
+                    print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {rays[k]}")
+        print(f"seed {seed}: {sc.num_entries} entries, root {root}, hits {(want['prim_id'] != rt.MISS).mean():.2f} ok", flush=True)
+    print("mismatching batches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
