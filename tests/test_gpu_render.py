@@ -8,7 +8,7 @@ within 2 %.  Bound: RMSE(gpu, oracle) <= 1.10 * RMSE(oracle, oracle')."""
 import numpy as np
 import pytest
 
-from helpers import asset, mirror, product_camera
+from helpers import asset, mirror, product_camera, random_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -258,3 +258,14 @@ def test_depth_extremes(rt, ob, ctx):
         sc.render(cam, rt.Scene.params(64, 48, 1, 65, osc.sky))
     with pytest.raises(rt.RtError):
         sc.render(cam, rt.Scene.params(64, 48, 1, 0, osc.sky))
+
+
+@pytest.mark.parametrize("root", [0, 2])
+def test_random_scene_image(rt, ob, ctx, root):
+    """Every material kind at once (lambert with and without normal shading, metal with fuzz 0.3 and
+    1.0, glass, emitters), spheres and meshes mixed, thin-lens camera with a real aperture, Bvh and
+    list roots: image statistics against the oracle."""
+    mats, objects, _ = random_scene(ob, 40 + root, n_spheres=60, n_meshes=3, tris_per_mesh=80, extent=6.0)
+    cam = ((0.0, -16.0, 3.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.4, 16.0)
+    osc = ob.Scene.from_description(mats, objects, root, camera=cam, sky=0.8)
+    _compare(rt, ob, ctx, osc, 112, 80, 48, 8, clip=6.0)
