@@ -549,7 +549,28 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     int last_pipe = -1;
     for (size_t tile0 = 0; tile0 < n_tiles; tile0 += tiles_per_batch) {
         const size_t nt = std::min(tiles_per_batch, n_tiles - tile0);
-        for (uint32_t s0 = 0; s0 < n_samples; s0 += samples_per_batch, batch++) {
+        // sample chunks of this tile group; the very last ones of the call taper off (1/2, 1/2, 1/4,
+        // 1/4, 1/8 x 4 of a chunk, not below 1 Mi paths): the call ends when the slowest wave of its
+        // last batch does, and that wave's life is proportional to the batch
+        std::vector<uint32_t> chunks;
+        for (uint32_t s0 = 0; s0 < n_samples; s0 += samples_per_batch)
+            chunks.push_back(std::min(samples_per_batch, n_samples - s0));
+        if (n_pipes > 1 && tile0 + tiles_per_batch >= n_tiles && chunks.size() >= 4 && !std::getenv("RT_NO_TAPER")) {
+            const uint32_t min_chunk = (uint32_t)std::max<size_t>(1, ((size_t)1 << 20) / (nt * 64));
+            uint32_t rest = chunks[chunks.size() - 1] + chunks[chunks.size() - 2];
+            chunks.resize(chunks.size() - 2);
+            const uint32_t full = samples_per_batch;
+            for (uint32_t div : {2u, 2u, 4u, 4u, 8u, 8u, 8u, 8u}) {
+                const uint32_t c = std::min(rest, std::max(min_chunk, full / div));
+                if (c == 0) break;
+                chunks.push_back(c);
+                rest -= c;
+            }
+            if (rest) chunks.back() += rest;
+        }
+        uint32_t s0 = 0;
+        for (size_t ci = 0; ci < chunks.size(); s0 += chunks[ci], ci++, batch++) {
+            const uint32_t chunk = chunks[ci];
             const int k = (int)(batch % (size_t)n_pipes);
             Pipe& pp = ctx->pipes[k];
             hipStream_t st = pp.stream;
@@ -561,7 +582,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.tile_base = (uint32_t)tile0;
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin + s0;
-            g.n_samples = std::min(samples_per_batch, n_samples - s0);
+            g.n_samples = chunk;
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
             segments(g);
