@@ -8,7 +8,8 @@
 //           into the next ray buffer.
 // Every wave owns one segment of the batch's path slots from raygen to the last bounce, so
 // queueing and compaction use only the wave's own ballot and lane prefix: no atomics, no
-// barriers, deterministic ray order.
+// barriers, deterministic ray order.  By default one kernel (k_path) carries a segment through
+// all its stages; k_raygen / k_trace / k_shade are the same stages as separate launches.
 //
 // Intersection arithmetic must equal the reference's IEEE f32 results bit for bit, so this file
 // is built with -ffp-contract=off (no FMA), and relies on hipcc's default correctly rounded
