@@ -365,6 +365,8 @@ int rt_scene_commit(rt_scene* s) {
         const char* e = getenv("RT_PRIM_WAIT");
         s->dev.prim_wait = e ? (uint32_t)atoi(e) : 8u;   // 8: best of {1, 8, 16, 24, 40, 64} on the sphere and OBJ scenes
     }
+    s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 32u <= LDS_WALK_MAX_BYTES &&
+                       !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     rc = apply_traversal(s, s->traversal);
     if (rc) return rc;
     // the host copies of the geometry are no longer needed
@@ -503,7 +505,10 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
     }
-    const uint32_t wave_target = s->dev.sweep ? ctx->wave_target_sweep : ctx->wave_target;
+    // (the walk out of LDS runs 8-wave workgroups, which even out less finely: a quarter of the segments)
+    const bool lds_walk = s->dev.lds_walk && !s->dev.sweep && !s->dev.ordered && !staged;
+    const uint32_t wave_target = s->dev.sweep ? ctx->wave_target_sweep
+                                              : (lds_walk && !std::getenv("RT_WAVE_TARGET") ? ctx->wave_target / 4 : ctx->wave_target);
     auto segments = [&](BatchGeom& g) {        // one wave per segment, a multiple of 64 slots long
         g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + wave_target - 1) / wave_target + 63u) / 64u * 64u);
         g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;

@@ -488,11 +488,12 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
     out[r] = h;
 }
 
-// per-lane stacks of the ordered walk: stack_depth * 64 words per wave (dynamic LDS)
+// dynamic LDS: the per-lane stacks of the ordered walk (stack_depth * 64 words per wave), or the
+// workgroup's copy of the unit array when a small scene is walked out of LDS
 extern __shared__ uint32_t lds_stack[];
 
 // SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene),
-//        3 = ordered per-lane walk
+//        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only)
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -778,6 +779,8 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                 closest_hit_ordered<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait,
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, lane, valid, a.x,
                                            a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 4)
+                closest_hit<COUNT>((const float4*)lds_stack, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
@@ -990,11 +993,26 @@ __device__ __forceinline__ void stage_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// SWEEP == 4: a scene of a few tens of KB is walked per lane out of LDS.  Eight waves form a
+// workgroup (RT_LDS_BLOCK threads) only to share one copy of the unit array; after the copy they
+// never synchronise again.  The per-lane walk spends 60 % of its wave time waiting for entries
+// from L2; LDS answers in a fraction of that.
+#ifndef RT_LDS_BLOCK
+#define RT_LDS_BLOCK 512
+#endif
 template <int SWEEP>
-__global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(SWEEP == 4 ? RT_LDS_BLOCK : RT_WAVE)
+    __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
        uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
-    const uint32_t seg = blockIdx.x * RT_WPB + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t wpb = SWEEP == 4 ? RT_LDS_BLOCK / 64 : RT_WPB;
+    const uint32_t seg = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (SWEEP == 4) {
+        const float4* src = (const float4*)sc.units;
+        float4* dst = (float4*)lds_stack;
+        for (uint32_t i = threadIdx.x; i < 2u * sc.n_units; i += RT_LDS_BLOCK) dst[i] = src[i];
+        __syncthreads();                       // before any wave of the workgroup may leave
+    }
     if (seg >= g.n_seg) return;
 #ifdef RT_STAMPS
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
@@ -1146,6 +1164,13 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
 #define RT_PATH(SWP)                                                                                    \
     hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
+    if (sc.lds_walk && !sc.ordered && !sc.sweep) {
+        const size_t bytes = (size_t)sc.n_units * 32u;
+        hipLaunchKernelGGL((k_path<4>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK),
+                           bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min,
+                           sky_intensity RT_STAMP_ARG);
+        return check_launch();
+    }
     const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
     if (mode == 3) RT_PATH(3);
     else if (mode == 2) RT_PATH(2);

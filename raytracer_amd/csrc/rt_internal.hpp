@@ -96,10 +96,14 @@ struct DevScene {
     uint32_t prim_wait;       // per-lane walk: lanes that must stand at primitives before their routine runs
     uint32_t ordered;         // 1: near-child-first walk with a per-lane stack (not the reference's visiting order)
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
+    uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default
 constexpr uint32_t SWEEP_MAX_ENTRIES = 192;
+// unit arrays up to this size are copied to LDS by every 8-wave workgroup of the per-lane walk
+// (three such workgroups fit the 160 KB of a CU: 6 waves per SIMD)
+constexpr uint32_t LDS_WALK_MAX_BYTES = 52u * 1024u;
 
 constexpr uint32_t MAX_DEPTH = 64;
 
