@@ -361,12 +361,13 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
-    {
-        const char* e = getenv("RT_PRIM_WAIT");
-        s->dev.prim_wait = e ? (uint32_t)atoi(e) : 8u;   // 8: best of {1, 8, 16, 24, 40, 64} on the sphere and OBJ scenes
-    }
     s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 32u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
+    {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
+        // on the sphere and OBJ scenes, 8 when entries come from memory, 4 when they come from LDS
+        const char* e = getenv("RT_PRIM_WAIT");
+        s->dev.prim_wait = e ? (uint32_t)atoi(e) : (s->dev.lds_walk ? 4u : 8u);
+    }
     rc = apply_traversal(s, s->traversal);
     if (rc) return rc;
     // the host copies of the geometry are no longer needed
