@@ -141,8 +141,10 @@ int rt_scene_set_root(rt_scene* scene, int root_kind);
  * entries in the same order with the same arithmetic as the reference's recursion
  * (shape.rs:142-158, 292-324) and give bit-identical hits; they differ in speed only.
  * PER_LANE: every lane follows its own cursor (any scene size).  SWEEP: the wave sweeps the
- * entry array once with scalar fetches (small scenes).  AUTO picks one of these two by scene
- * size.
+ * entry array once with scalar fetches (small scenes).  AUTO picks one of these two: the walk
+ * above 192 entries; below, the first render of the scene times both on a small probe batch of
+ * its own frame and keeps the faster (a closed room favours the sweep, scattered objects the
+ * walk).
  * ORDERED is opt-in and has no counterpart in the reference: the same trees, the same box and
  * primitive tests, but at every box the child nearer along the ray is visited first (per-lane
  * stack), so the narrowed t_max culls far more boxes.  The closest hit is the same primitive and

@@ -107,6 +107,7 @@ struct rt_scene {
     int root_kind = RT_ROOT_BVH;
     int traversal = RT_TRAVERSAL_AUTO;
     bool ordered_ok = false;
+    bool auto_tuned = false;            // AUTO has timed the sweep against the walk out of LDS
     bool committed = false;
     FlatScene flat;
     DeviceBuffer d_entries, d_units, d_geo, d_meta, d_mats;
@@ -296,6 +297,7 @@ static int apply_traversal(rt_scene* s, int mode) {
     if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
+    s->auto_tuned = false;
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     return RT_OK;
@@ -505,6 +507,55 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         tiles_per_batch = std::min(n_tiles, std::max<size_t>(1, max_paths / 64));
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
+    }
+    // AUTO on a scene small enough for both the wave sweep and the walk out of LDS: which one is
+    // faster depends on how much of the scene a ray visits (a closed room: the sweep, by 1.5x;
+    // scattered objects under a sky: the walk, by 1.2-1.5x), so the first render times both on a
+    // probe batch of its own frame (<= 1 Mi paths, written to the pipeline's buffers only) and the
+    // scene keeps the winner.  Both give the same frame bit for bit.
+    if (s->traversal == RT_TRAVERSAL_AUTO && !s->auto_tuned && !staged && s->dev.sweep && s->dev.lds_walk &&
+        !std::getenv("RT_NO_AUTOTUNE")) {
+        float ms[2] = {0.0f, 0.0f};
+        for (int form = 0; form < 2; form++) {             // 0: sweep, 1: per-lane walk out of LDS
+            s->dev.sweep = form == 0 ? 1u : 0u;
+            const uint32_t target = form == 0 ? ctx->wave_target_sweep : ctx->wave_target / 4;
+            BatchGeom g;
+            g.width = p->width; g.height = p->height;
+            g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
+            g.tiles_x = tiles_x;
+            g.tile_base = 0;
+            const size_t nt = std::min<size_t>(n_tiles, 2048);
+            g.n_pix_slots = (uint32_t)(nt * 64);
+            g.sample_base = p->sample_begin;
+            g.n_samples = std::min<uint32_t>(n_samples, 8u);
+            g.n_slots = g.n_pix_slots * g.n_samples;
+            g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
+            g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + target - 1) / target + 63u) / 64u * 64u);
+            g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
+            Pipe& pp = ctx->pipes[0];
+            rc = ensure_capacity(ctx, pp, g.n_slots, g.n_seg);
+            if (rc) return rc;
+            RenderBuffers rb;
+            rb.hits = pp.hits.p;
+            for (int q = 0; q < 3; q++) rb.queue[q] = (uint32_t*)pp.queue[q].p;
+            rb.Lbuf = pp.lbuf.p;
+            rb.totals = (Totals*)ctx->totals.p;
+            rb.capacity = pp.capacity;
+            rb.segcnt = (uint32_t*)pp.segcnt.p;
+            rb.qcnt = (uint32_t*)pp.qcnt.p;
+            rb.cur = RayBuffers{pp.rayA[0].p, pp.rayB[0].p, pp.rayC[0].p};
+            rb.next = RayBuffers{pp.rayA[1].p, pp.rayB[1].p, pp.rayC[1].p};
+            for (int rep = 0; rep < 2; rep++) {            // the second run is the timed one
+                HIP_TRY(hipEventRecord(ctx->ev_begin, pp.stream));
+                if (launch_path(ctx->cfg(0), s->dev, *cam, g, p->seed, rb, p->max_bounces, p->t_min, p->sky_intensity))
+                    return fail(RT_ERR_DEVICE, "path kernel launch failed");
+                HIP_TRY(hipEventRecord(ctx->ev_end, pp.stream));
+            }
+            HIP_TRY(hipStreamSynchronize(pp.stream));
+            HIP_TRY(hipEventElapsedTime(&ms[form], ctx->ev_begin, ctx->ev_end));
+        }
+        s->dev.sweep = ms[0] <= ms[1] ? 1u : 0u;
+        s->auto_tuned = true;
     }
     // (the walk out of LDS runs 8-wave workgroups, which even out less finely: a quarter of the segments)
     const bool lds_walk = s->dev.lds_walk && !s->dev.sweep && !s->dev.ordered && !staged;
