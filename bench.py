@@ -135,6 +135,8 @@ def main():
                     help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--build", choices=["reference", "sah"], default="reference",
+                    help="mesh trees: the reference's median split (exact visiting order) or the opt-in SAH split")
     ap.add_argument("--staged", action="store_true",
                     help="one launch per stage and depth (times the closest-hit kernel alone) instead of one kernel per batch")
     ap.add_argument("--force-dist", action="store_true",
@@ -158,6 +160,7 @@ def main():
         width, height = (int(v) for v in args.size.lower().split("x"))
 
     ctx = rt.Context(local)
+    rt.set_default_build(rt.BUILD_SAH if args.build == "sah" else rt.BUILD_REFERENCE)
     t0 = time.time()
     wld = make_world(ctx, kind)
     build_s = time.time() - t0

@@ -137,6 +137,19 @@ int rt_scene_add_spheres(rt_scene* scene, const rt_sphere* spheres, size_t n);
  * identity; only the identity is supported (every shipped scene uses Mat4::identity()). */
 int rt_scene_add_mesh(rt_scene* scene, const rt_triangle* tris, size_t n, const float* xform);
 int rt_scene_set_root(rt_scene* scene, int root_kind);
+/* How the trees inside meshes are split (before rt_scene_commit).  REFERENCE: Mesh::build_bvh's
+ * stable median split on min[axis] (shape.rs:264-290): the reference's visiting order, hits exact
+ * by construction.  SAH is opt-in and has no counterpart in the reference: the same entry format,
+ * box padding and one triangle per leaf, but nodes are split where a binned surface-area
+ * heuristic is cheapest, which cuts the box tests per ray severalfold on meshes that mix large
+ * and small triangles.  The closest hit is the same primitive and the same t unless two
+ * primitives tie in t or a box test and a primitive test disagree within rounding (the
+ * reference resolves both by its visiting order). */
+enum { RT_BUILD_REFERENCE = 0, RT_BUILD_SAH = 1 };
+int rt_scene_set_build(rt_scene* scene, int build_mode);
+/* the build mode of scenes created from now on (process-wide; the scene constructors of
+ * rt_host.h create their scenes internally and take it from here) */
+int rt_set_default_build(int build_mode);
 /* How the closest-hit kernel walks the flattened trees.  PER_LANE and SWEEP visit the same
  * entries in the same order with the same arithmetic as the reference's recursion
  * (shape.rs:142-158, 292-324) and give bit-identical hits; they differ in speed only.

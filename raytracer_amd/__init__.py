@@ -28,6 +28,7 @@ MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED = 0, 1, 2, 3
+BUILD_REFERENCE, BUILD_SAH = 0, 1
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
 DEFAULT_SEED = 0x9E3779B97F4A7C15
@@ -92,6 +93,8 @@ def _load():
         "rt_scene_add_mesh": (i32, [vp, vp, sz, vp]),
         "rt_scene_set_root": (i32, [vp, i32]),
         "rt_scene_set_traversal": (i32, [vp, i32]),
+        "rt_scene_set_build": (i32, [vp, i32]),
+        "rt_set_default_build": (i32, [i32]),
         "rt_scene_commit": (i32, [vp]),
         "rt_scene_num_prims": (sz, [vp]),
         "rt_scene_num_entries": (sz, [vp]),
@@ -138,7 +141,8 @@ lib = _load()
 ABI_SYMBOLS = [
     "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_context_stream",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
-    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_traversal", "rt_scene_commit",
+    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
+    "rt_scene_set_traversal", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
     "rt_scene_get_units", "rt_trace",
     "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
@@ -231,7 +235,7 @@ class Scene:
         s._borrowed = True
         return s
 
-    def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH):
+    def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH, build=None):
         self.ctx = ctx
         self._borrowed = False
         h = C.c_void_p()
@@ -250,6 +254,8 @@ class Scene:
             else:
                 raise ValueError(kind)
         _check(lib.rt_scene_set_root(self.h, root_kind))
+        if build is not None:
+            _check(lib.rt_scene_set_build(self.h, build))
         _check(lib.rt_scene_commit(self.h))
 
     def close(self):
@@ -438,6 +444,11 @@ class World:
         st = Stats()
         _check(lib.rt_world_render(self.h, width, height, spp, max_bounces, seed, _ptr(acc), C.byref(st)))
         return acc, st.as_dict()
+
+
+def set_default_build(mode):
+    """Build mode (BUILD_REFERENCE / BUILD_SAH) of scenes created from now on, World constructors included."""
+    _check(lib.rt_set_default_build(mode))
 
 
 def progressive_schedule(spp):

@@ -20,6 +20,7 @@ using namespace rtamd;
 namespace {
 
 thread_local std::string g_last_error;
+std::atomic<int> g_default_build{RT_BUILD_REFERENCE};   // rt_set_default_build
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -105,6 +106,7 @@ struct rt_scene {
     std::vector<rt_material> mats;
     std::vector<SceneObject> objects;
     int root_kind = RT_ROOT_BVH;
+    int build_mode = RT_BUILD_REFERENCE;
     int traversal = RT_TRAVERSAL_AUTO;
     bool ordered_ok = false;
     bool auto_tuned = false;            // AUTO has timed the sweep against the walk out of LDS
@@ -234,6 +236,7 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
     if (ctx && ctx->destroyed) return fail(RT_ERR_STATE, "rt_scene_create: the context has been destroyed");
     *out = new rt_scene();
     (*out)->ctx = ctx;
+    (*out)->build_mode = g_default_build.load();
     if (ctx) ctx->refs.fetch_add(1);
     return RT_OK;
 }
@@ -303,6 +306,20 @@ static int apply_traversal(rt_scene* s, int mode) {
     return RT_OK;
 }
 
+int rt_set_default_build(int build_mode) {
+    if (build_mode != RT_BUILD_REFERENCE && build_mode != RT_BUILD_SAH) return fail(RT_ERR_INVALID, "unknown build mode");
+    g_default_build.store(build_mode);
+    return RT_OK;
+}
+
+int rt_scene_set_build(rt_scene* s, int build_mode) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_build: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (build_mode != RT_BUILD_REFERENCE && build_mode != RT_BUILD_SAH) return fail(RT_ERR_INVALID, "unknown build mode");
+    s->build_mode = build_mode;
+    return RT_OK;
+}
+
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
     if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_ORDERED) return fail(RT_ERR_INVALID, "unknown traversal mode");
@@ -317,7 +334,7 @@ int rt_scene_set_traversal(rt_scene* s, int mode) {
 int rt_scene_commit(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->flat);
+    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->build_mode, s->flat);
     if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
     rt_context* ctx = s->ctx;
     s->dev.n_entries = (uint32_t)s->flat.n_entries();

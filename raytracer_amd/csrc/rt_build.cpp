@@ -47,6 +47,8 @@ struct Builder {
     // scratch for the mesh currently being emitted
     const SceneObject* mesh = nullptr;
     std::vector<float> tri_min;                // Triangle::get_aabb().min per triangle (3 floats)
+    std::vector<float> tri_cen;                // SAH build: 2 x centre of every triangle's box
+    bool sah = false;                          // split meshes by the surface-area heuristic
 
     Builder(const std::vector<rt_material>& m, std::vector<SceneObject>& o, FlatScene& f)
         : mats(m), objects(o), out(f) {}
@@ -140,6 +142,94 @@ struct Builder {
         }
     }
 
+    // The opt-in tree: same entry format, boxes and leaves, but every node is split where a binned
+    // surface-area heuristic is cheapest instead of at the median of min[axis] (shape.rs:264-290).
+    // Big and small triangles then part ways near the root, which the median split never
+    // achieves (cornell_box.obj: every one of the upper 13 levels spans the room).
+    static float half_area(const Box& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    Box tight_box(const uint32_t* idx, size_t n) const {
+        Box b = box_infinity();
+        for (size_t i = 0; i < n; i++) {
+            const rt_triangle& t = mesh->tris[idx[i]];
+            grow_point(b, t.p[0]); grow_point(b, t.p[1]); grow_point(b, t.p[2]);
+        }
+        return b;
+    }
+    void fill_mesh_range_sah(uint32_t* idx, size_t n, size_t at, int fork_levels) {
+        if (n == 0) return;
+        if (n == 1) { write_triangle(at, idx[0]); return; }
+        write_box(at, padded_box(idx, n), at + mesh_entries(n));
+        size_t half = n / 2;
+        if (n > 2) {
+            constexpr int BINS = 16;
+            const float* cen = tri_cen.data();
+            float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (size_t i = 0; i < n; i++)
+                for (int k = 0; k < 3; k++) {
+                    clo[k] = std::min(clo[k], cen[idx[i] * 3 + k]);
+                    chi[k] = std::max(chi[k], cen[idx[i] * 3 + k]);
+                }
+            float best = INFINITY;
+            int best_axis = -1, best_bin = 0;
+            float best_scale = 0.0f;
+            for (int k = 0; k < 3; k++) {
+                const float ext = chi[k] - clo[k];
+                if (!(ext > 0.0f)) continue;
+                const float scale = (float)BINS * (1.0f - 1e-6f) / ext;
+                Box bb[BINS];
+                size_t cnt[BINS] = {};
+                for (int j = 0; j < BINS; j++) bb[j] = box_infinity();
+                for (size_t i = 0; i < n; i++) {
+                    const int j = std::min(BINS - 1, std::max(0, (int)((cen[idx[i] * 3 + k] - clo[k]) * scale)));
+                    const rt_triangle& t = mesh->tris[idx[i]];
+                    grow_point(bb[j], t.p[0]); grow_point(bb[j], t.p[1]); grow_point(bb[j], t.p[2]);
+                    cnt[j]++;
+                }
+                float right_area[BINS];
+                size_t right_cnt[BINS];
+                Box acc = box_infinity();
+                size_t c = 0;
+                for (int j = BINS - 1; j > 0; j--) {
+                    if (cnt[j]) acc = surrounding(acc, bb[j]);
+                    c += cnt[j];
+                    right_area[j] = c ? half_area(acc) : 0.0f;
+                    right_cnt[j] = c;
+                }
+                acc = box_infinity();
+                c = 0;
+                for (int j = 0; j + 1 < BINS; j++) {       // split between bin j and j + 1
+                    if (cnt[j]) acc = surrounding(acc, bb[j]);
+                    c += cnt[j];
+                    if (c == 0 || right_cnt[j + 1] == 0) continue;
+                    const float cost = half_area(acc) * (float)c + right_area[j + 1] * (float)right_cnt[j + 1];
+                    if (cost < best) { best = cost; best_axis = k; best_bin = j; best_scale = scale; }
+                }
+            }
+            if (best_axis >= 0) {
+                const int k = best_axis;
+                const float lo = clo[k];
+                uint32_t* mid = std::partition(idx, idx + n, [&](uint32_t t) {
+                    const int j = std::min(BINS - 1, std::max(0, (int)((cen[t * 3 + k] - lo) * best_scale)));
+                    return j <= best_bin;
+                });
+                half = (size_t)(mid - idx);
+                if (half == 0 || half == n) half = n / 2;  // (cannot happen: both sides were non-empty)
+            }
+        }
+        const size_t left_at = at + 1, right_at = left_at + mesh_entries(half);
+        if (fork_levels > 0 && n >= 65536) {
+            std::thread left([=]() { fill_mesh_range_sah(idx, half, left_at, fork_levels - 1); });
+            fill_mesh_range_sah(idx + half, n - half, right_at, fork_levels - 1);
+            left.join();
+        } else {
+            fill_mesh_range_sah(idx, half, left_at, 0);
+            fill_mesh_range_sah(idx + half, n - half, right_at, 0);
+        }
+    }
+
     void emit_object(uint32_t oi) {
         const SceneObject& o = objects[oi];
         if (!o.is_mesh) { push_sphere(o); return; }
@@ -157,7 +247,16 @@ struct Builder {
         const size_t at = out.n_entries();
         out.entries.resize(out.entries.size() + mesh_entries(n) * ENTRY_FLOATS, 0.0f);
         // Mesh::hit enters at the root node (shape.rs:455); up to 2^5 threads on a big mesh
-        fill_mesh_range(idx.data(), n, 0, at, 5);
+        if (sah) {
+            tri_cen.resize(n * 3);
+            for (size_t i = 0; i < n; i++) {
+                const Box tb = tight_box(&idx[i], 1);
+                for (int k = 0; k < 3; k++) tri_cen[i * 3 + k] = tb.lo[k] + tb.hi[k];
+            }
+            fill_mesh_range_sah(idx.data(), n, at, 5);
+        } else {
+            fill_mesh_range(idx.data(), n, 0, at, 5);
+        }
         mesh = nullptr;
     }
 
@@ -283,7 +382,7 @@ void pack_units(FlatScene& out) {
 }  // namespace
 
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             int root_kind, FlatScene& out) {
+                             int root_kind, int build_mode, FlatScene& out) {
     out = FlatScene();
     if (mats.empty()) return "no materials set";
     if (mats.size() > MAT_MASK) return "too many materials";
@@ -292,6 +391,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
 
     // primitive ids, per-primitive shading data, per-object boxes
     Builder b(mats, objects, out);
+    b.sah = build_mode == RT_BUILD_SAH;
     uint64_t prim = 0;
     for (SceneObject& o : objects) {
         o.prim_base = (uint32_t)prim;

@@ -74,8 +74,10 @@ struct SceneObject {
 
 // Builds the reference-topology trees and flattens them.  Returns an empty string on success,
 // otherwise the error message.
+// build_mode RT_BUILD_SAH replaces the reference's median split inside meshes by a binned
+// surface-area-heuristic split (same entry format, same box padding, one triangle per leaf).
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             int root_kind, FlatScene& out);
+                             int root_kind, int build_mode, FlatScene& out);
 
 // ---------------------------------------------------------------------------------------------
 // Device side

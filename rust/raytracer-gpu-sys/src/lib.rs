@@ -14,6 +14,12 @@ pub const RT_MAT_FLAG_NORMAL_SHADING: u32 = 1;
 pub const RT_ROOT_BVH: c_int = 0;
 pub const RT_ROOT_SINGLE: c_int = 1;
 pub const RT_ROOT_LIST: c_int = 2;
+pub const RT_TRAVERSAL_AUTO: c_int = 0;
+pub const RT_TRAVERSAL_PER_LANE: c_int = 1;
+pub const RT_TRAVERSAL_SWEEP: c_int = 2;
+pub const RT_TRAVERSAL_ORDERED: c_int = 3;
+pub const RT_BUILD_REFERENCE: c_int = 0;
+pub const RT_BUILD_SAH: c_int = 1;
 pub const RT_RENDER_PROFILE: u32 = 1;
 pub const RT_RENDER_COUNT_VISITS: u32 = 2;
 pub const RT_RENDER_STAGED: u32 = 4;
@@ -68,6 +74,8 @@ extern "C" {
     pub fn rt_scene_add_mesh(scene: *mut rt_scene, tris: *const rt_triangle, n: usize, xform: *const f32) -> c_int;
     pub fn rt_scene_set_root(scene: *mut rt_scene, root_kind: c_int) -> c_int;
     pub fn rt_scene_set_traversal(scene: *mut rt_scene, mode: c_int) -> c_int;
+    pub fn rt_scene_set_build(scene: *mut rt_scene, mode: c_int) -> c_int;
+    pub fn rt_set_default_build(mode: c_int) -> c_int;
     pub fn rt_scene_commit(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_num_prims(scene: *const rt_scene) -> usize;
     pub fn rt_scene_num_entries(scene: *const rt_scene) -> usize;

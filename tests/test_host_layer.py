@@ -314,6 +314,46 @@ def test_child_links_of_the_ordered_walk(rt, ob):
     assert visits < st["box_tests"] + st["tri_tests"] + st["sph_tests"]
 
 
+def test_sah_build_keeps_format_and_hits(rt, ob):
+    """RT_BUILD_SAH moves only the split positions of mesh trees: every triangle is still one leaf,
+    every box still has exactly two children and the padded union of what is below it, the entry
+    count is unchanged, and both walks over the entries find the oracle's closest hits."""
+    mats, objects, _ = random_scene(ob, 41, n_spheres=12, n_meshes=2, tris_per_mesh=57, extent=5.0)
+    osc = ob.Scene.from_description(mats, objects, 0)
+    ref = rt.Scene(None, mats, objects, 0)
+    sah = rt.Scene(None, mats, objects, 0, build=rt.BUILD_SAH)
+    ent, u = sah.entries(), sah.entries().view(np.uint32)
+    assert len(ent) == ref.num_entries and sah.num_prims == ref.num_prims
+    assert not np.array_equal(ent, ref.entries())
+    tags = u[:, 3] >> 30
+    assert sorted(u[tags != 0, 7].tolist()) == list(range(sah.num_prims))       # each primitive once
+    end_of = lambda i: int(u[i, 3] & 0x3FFFFFFF) if tags[i] == 0 else i + 1
+    pad = np.float32(0.0001)
+    for i in np.nonzero(tags == 0)[0]:
+        end = end_of(i)
+        first = end_of(i + 1)                              # one child (an object-level leaf) or two
+        assert first == end or end_of(first) == end
+        kids = np.arange(i + 1, end)
+        tri = kids[tags[kids] == 1]
+        if len(kids) + 1 == 2 * len(tri) - 1:              # a node of a mesh tree: n leaves, n - 1 boxes
+            p0 = ent[tri, 0:3]
+            pts = np.concatenate([p0, p0 + ent[tri, 4:7], p0 + ent[tri, 8:11]])
+            # vertices are stored as p0 and two edges; the sums round, so compare loosely
+            np.testing.assert_allclose(ent[i, 0:3], pts.min(axis=0) - pad, atol=1e-5)
+            np.testing.assert_allclose(ent[i, 4:7], pts.max(axis=0) + pad, atol=1e-5)
+    rays = random_rays(ob, 9, 300, -6.0, 6.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    for k in range(len(rays)):
+        for walk in (_walk, _walk_ordered):
+            prim, t = walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))[:2]
+            assert prim == want["prim_id"][k]
+            if prim != 0xFFFFFFFF:
+                assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+    with pytest.raises(rt.RtError):
+        rt.Scene(None, mats, objects, 0, build=7)
+
+
 def test_entry_layout_small_cases(rt, ob):
     mats = np.zeros(2, dtype=rt.material_dt)
     mats["kind"] = [rt.MAT_LAMBERT, rt.MAT_METAL]
