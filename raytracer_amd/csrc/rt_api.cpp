@@ -109,7 +109,9 @@ struct rt_scene {
     int build_mode = RT_BUILD_REFERENCE;
     int traversal = RT_TRAVERSAL_AUTO;
     bool ordered_ok = false;
-    bool auto_tuned = false;            // AUTO has timed the sweep against the walk out of LDS
+    bool auto_tuned = false;            // the first render has timed the forms of the closest-hit loop that apply
+    uint32_t env_prim_wait = 0;         // RT_PRIM_WAIT, 0 when unset
+    uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
     bool committed = false;
     FlatScene flat;
     DeviceBuffer d_entries, d_units, d_geo, d_meta, d_mats;
@@ -301,6 +303,8 @@ static int apply_traversal(rt_scene* s, int mode) {
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
     s->auto_tuned = false;
+    s->dev.refill = s->env_refill;
+    s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : (s->dev.lds_walk ? 4u : 8u);
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     return RT_OK;
@@ -385,7 +389,12 @@ int rt_scene_commit(rt_scene* s) {
     {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
         // on the sphere and OBJ scenes, 8 when entries come from memory, 4 when they come from LDS
         const char* e = getenv("RT_PRIM_WAIT");
-        s->dev.prim_wait = e ? (uint32_t)atoi(e) : (s->dev.lds_walk ? 4u : 8u);
+        s->env_prim_wait = e ? (uint32_t)std::max(1, atoi(e)) : 0u;
+        s->dev.prim_wait = e ? s->env_prim_wait : (s->dev.lds_walk ? 4u : 8u);
+    }
+    {
+        const char* e = getenv("RT_REFILL");
+        s->env_refill = e ? (uint32_t)std::min(64, std::max(0, atoi(e))) : 0u;
     }
     rc = apply_traversal(s, s->traversal);
     if (rc) return rc;
@@ -479,7 +488,11 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
 
     const bool profile = (p->flags & RT_RENDER_PROFILE) != 0;
     const bool count = (p->flags & RT_RENDER_COUNT_VISITS) != 0;
+#ifdef RT_UTIL                                 // diagnostic build: the fused kernel counts visits itself
+    const bool staged = (p->flags & RT_RENDER_STAGED) != 0 || std::getenv("RT_STAGED") != nullptr;
+#else
     const bool staged = count || (p->flags & RT_RENDER_STAGED) != 0 || std::getenv("RT_STAGED") != nullptr;
+#endif
     const uint32_t rw = p->x1 - p->x0, rh = p->y1 - p->y0;
     const uint32_t tiles_x = (rw + 7) / 8, tiles_y_all = (rh + 7) / 8;
     const uint32_t band_count = p->band_count > 1 ? p->band_count : 1;
@@ -525,29 +538,50 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         samples_per_batch =
             (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
     }
-    // AUTO on a scene small enough for both the wave sweep and the walk out of LDS: which one is
-    // faster depends on how much of the scene a ray visits (a closed room: the sweep, by 1.5x;
-    // scattered objects under a sky: the walk, by 1.2-1.5x), so the first render times both on a
-    // probe batch of its own frame (<= 1 Mi paths, written to the pipeline's buffers only) and the
-    // scene keeps the winner.  Both give the same frame bit for bit.
-    if (s->traversal == RT_TRAVERSAL_AUTO && !s->auto_tuned && !staged && s->dev.sweep && s->dev.lds_walk &&
-        !std::getenv("RT_NO_AUTOTUNE")) {
-        float ms[2] = {0.0f, 0.0f};
-        for (int form = 0; form < 2; form++) {             // 0: sweep, 1: per-lane walk out of LDS
-            s->dev.sweep = form == 0 ? 1u : 0u;
-            const uint32_t target = form == 0 ? ctx->wave_target_sweep : ctx->wave_target / 4;
+    // Forms of the closest-hit loop that give the same frame bit for bit but whose speed depends on
+    // the scene are timed against each other on the scene's first render, on a probe batch of the
+    // frame itself (<= 4 Mi paths, written to the pipeline's buffers only); the scene keeps the winner.
+    //  - small scenes (AUTO only): wave sweep against the per-lane walk out of LDS.  How much of the
+    //    scene a ray visits decides (a closed room: the sweep, by 1.5x; scattered objects under a
+    //    sky: the walk, by 1.2-1.5x).
+    //  - scenes walked per lane from memory: plain loop against the loop that refills idle lanes.
+    //    Walks of very uneven length decide (a room with one dense mesh: refill, by 1.3-1.7x; a
+    //    uniform triangle soup: plain, by 1.1-1.2x).
+    struct Form { uint32_t sweep, refill, prim_wait; };
+    auto form_target = [&](const DevScene& d) -> uint32_t {
+        if (d.sweep) return ctx->wave_target_sweep;
+        if (std::getenv("RT_WAVE_TARGET") || d.ordered || staged) return ctx->wave_target;
+        if (d.lds_walk) return ctx->wave_target / 4;   // 8-wave workgroups even out less finely
+        return d.refill ? ctx->wave_target / 2 : ctx->wave_target;   // refill wants long segments
+    };
+    auto seg_len_for = [&](size_t n_slots, uint32_t target) -> uint32_t {
+        return std::max<uint32_t>(64u, (uint32_t)(((n_slots + target - 1) / target + 63u) / 64u * 64u));
+    };
+    if (!s->auto_tuned && !staged && !s->dev.ordered && !std::getenv("RT_NO_AUTOTUNE")) {
+        std::vector<Form> forms;
+        const uint32_t wait_mem = s->env_prim_wait ? s->env_prim_wait : 8u, wait_refill = s->env_prim_wait ? s->env_prim_wait : 16u;
+        if (s->traversal == RT_TRAVERSAL_AUTO && s->dev.sweep && s->dev.lds_walk)
+            forms = {Form{1u, 0u, s->dev.prim_wait}, Form{0u, 0u, s->dev.prim_wait}};
+        else if (!s->dev.sweep && !s->dev.lds_walk && !std::getenv("RT_REFILL"))
+            forms = {Form{0u, 0u, wait_mem}, Form{0u, 16u, wait_refill}};
+        size_t best = 0;
+        float best_ms = 0.0f;
+        for (size_t f = 0; f < forms.size(); f++) {
+            s->dev.sweep = forms[f].sweep; s->dev.refill = forms[f].refill; s->dev.prim_wait = forms[f].prim_wait;
             BatchGeom g;
             g.width = p->width; g.height = p->height;
             g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
             g.tiles_x = tiles_x;
             g.tile_base = 0;
-            const size_t nt = std::min<size_t>(n_tiles, 2048);
+            const size_t nt = std::min<size_t>(tiles_per_batch, 4096);
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin;
-            g.n_samples = std::min<uint32_t>(n_samples, 8u);
+            g.n_samples = (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, ((size_t)4 << 20) / (nt * 64)));
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
-            g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + target - 1) / target + 63u) / 64u * 64u);
+            // segments as long as the real batches' (what the refill draws on), but not over 512, so
+            // that the probe still spreads over every wave slot of the chip
+            g.seg_len = std::min(512u, seg_len_for(tiles_per_batch * 64 * (size_t)samples_per_batch, form_target(s->dev)));
             g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
             Pipe& pp = ctx->pipes[0];
             rc = ensure_capacity(ctx, pp, g.n_slots, g.n_seg);
@@ -569,25 +603,29 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 HIP_TRY(hipEventRecord(ctx->ev_end, pp.stream));
             }
             HIP_TRY(hipStreamSynchronize(pp.stream));
-            HIP_TRY(hipEventElapsedTime(&ms[form], ctx->ev_begin, ctx->ev_end));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+            if (f == 0 || ms < best_ms) { best = f; best_ms = ms; }
         }
-        s->dev.sweep = ms[0] <= ms[1] ? 1u : 0u;
+        if (!forms.empty()) {
+            s->dev.sweep = forms[best].sweep; s->dev.refill = forms[best].refill; s->dev.prim_wait = forms[best].prim_wait;
+        }
         s->auto_tuned = true;
     }
-    // (the walk out of LDS runs 8-wave workgroups, which even out less finely: a quarter of the segments)
-    const bool lds_walk = s->dev.lds_walk && !s->dev.sweep && !s->dev.ordered && !staged;
-    const uint32_t wave_target = s->dev.sweep ? ctx->wave_target_sweep
-                                              : (lds_walk && !std::getenv("RT_WAVE_TARGET") ? ctx->wave_target / 4 : ctx->wave_target);
+    const uint32_t wave_target = form_target(s->dev);
     auto segments = [&](BatchGeom& g) {        // one wave per segment, a multiple of 64 slots long
-        g.seg_len = std::max<uint32_t>(64u, ((g.n_slots + wave_target - 1) / wave_target + 63u) / 64u * 64u);
+        g.seg_len = seg_len_for(g.n_slots, wave_target);
         g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
     };
     {
         BatchGeom g0;
         g0.n_slots = (uint32_t)(tiles_per_batch * 64 * samples_per_batch);
         segments(g0);
+        // a shorter batch (a tapered chunk, the last tile group) is cut into shorter segments and may
+        // have more of them than the longest batch: never more than the wave target or one per 64 slots
+        const size_t seg_cap = std::max<size_t>(g0.n_seg, std::min<size_t>(wave_target, (g0.n_slots + 63u) / 64u));
         for (int k = 0; k < n_pipes; k++) {
-            rc = ensure_capacity(ctx, ctx->pipes[k], g0.n_slots, g0.n_seg);
+            rc = ensure_capacity(ctx, ctx->pipes[k], g0.n_slots, seg_cap);
             if (rc) return rc;
         }
     }
@@ -635,12 +673,13 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             chunks.resize(chunks.size() - 2);
             const uint32_t full = samples_per_batch;
             for (uint32_t div : {2u, 2u, 4u, 4u, 8u, 8u, 8u, 8u}) {
-                const uint32_t c = std::min(rest, std::max(min_chunk, full / div));
+                // never above a whole chunk: the pipelines' buffers are sized for that
+                const uint32_t c = std::min(rest, std::min(full, std::max(min_chunk, full / div)));
                 if (c == 0) break;
                 chunks.push_back(c);
                 rest -= c;
             }
-            if (rest) chunks.back() += rest;
+            for (; rest; rest -= std::min(rest, full)) chunks.push_back(std::min(rest, full));
         }
         uint32_t s0 = 0;
         for (size_t ci = 0; ci < chunks.size(); s0 += chunks[ci], ci++, batch++) {
@@ -660,6 +699,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
             segments(g);
+            if (g.n_slots > pp.capacity || (size_t)(MAX_DEPTH + 1) * g.n_seg * sizeof(uint32_t) > pp.segcnt.bytes ||
+                (size_t)3 * g.n_seg * sizeof(uint32_t) > pp.qcnt.bytes)
+                return fail(RT_ERR_STATE, "internal error: a batch is larger than the pipeline's buffers");
 
             RenderBuffers rb;
             rb.hits = pp.hits.p;

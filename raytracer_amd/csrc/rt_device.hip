@@ -130,6 +130,14 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
     }
 }
 
+// Diagnostic build only (-DRT_UTIL): the fused kernel counts visits too, and every lane adds one
+// to the sphere counter per loop trip of its wave (use on scenes without spheres):
+// (box + triangle visits) / that count is the share of lanes a trip of the walk works for.
+#ifdef RT_UTIL
+#define RT_UTIL_TRIP(cnt) (cnt).sph++
+#else
+#define RT_UTIL_TRIP(cnt)
+#endif
 // Per-lane walk of a whole wave (call converged; lanes without a ray pass valid = false).  Every
 // lane visits its own entries in the reference's order.  `ent` is the compact form of the entry
 // array: 32-byte units (two float4), a box or a sphere in one unit, a triangle in two (its v0v2
@@ -154,6 +162,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
         const bool at_prim = live && tag != TAG_BOX;
         const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
         if ((mb | mp) == 0ull) break;
+        RT_UTIL_TRIP(cnt);
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
@@ -719,6 +728,95 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
 constexpr uint32_t STAMP_SLOTS = 32, STAMP_WAVES = 16384;
 __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 #endif
+// The per-lane walk over a whole segment with idle lanes refilled.  Walks differ a lot in length
+// (a ray that crosses a dense mesh visits ten times the entries of one that meets a wall), and a
+// wave that takes 64 rays and runs until the longest walk ends issues most of its loads for a
+// handful of lanes: every wave-wide 16-byte load costs the CU's address unit 16 cycles whatever
+// the number of lanes in it, and that unit is what bounds the walk from memory.  Here a lane whose
+// walk has ended waits only until `refill_min` lanes are idle; these then finish their rays
+// (finish_ray + queueing) and take the next rays of the segment.  Every ray is still walked by one
+// lane in the reference's order; only which lane and when changes, and nothing downstream depends
+// on that (queues are compacted per kind, radiance is stored per path slot).
+template <bool COUNT>
+__device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent, uint32_t prim_wait,
+                                             uint32_t refill_min, const float4* __restrict__ mats,
+                                             const uint32_t* __restrict__ prim_meta, const float4* __restrict__ A,
+                                             const float4* __restrict__ B, const float4* __restrict__ C,
+                                             uint2* __restrict__ hits, uint32_t* __restrict__ q0,
+                                             uint32_t* __restrict__ q1, uint32_t* __restrict__ q2,
+                                             float4* __restrict__ Lbuf, uint32_t base, uint32_t n,
+                                             uint32_t last_depth, float t_min, float sky_intensity, uint32_t& n0,
+                                             uint32_t& n1, uint32_t& n2, Counts& cnt) {
+    LaneRay r;
+    lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
+    uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
+    bool has_ray = false, live = false;
+    uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+    for (;;) {
+        const unsigned long long m_live = __ballot(live);
+        const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
+        if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
+            uint32_t kind = 7u;
+            if (has_ray && !live) {
+                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t, r.best_prim,
+                                  last_depth, sky_intensity);
+                has_ray = false;
+            }
+            uint32_t pos;
+            pos = wave_append(kind == 0u, n0);
+            if (kind == 0u) q0[base + pos] = ray_i;
+            pos = wave_append(kind == 1u, n1);
+            if (kind == 1u) q1[base + pos] = ray_i;
+            pos = wave_append(kind == 2u, n2);
+            if (kind == 2u) q2[base + pos] = ray_i;
+            if (next >= n) {
+                if (m_live == 0ull) break;
+            } else {
+                const uint32_t j = next + lane_prefix(~m_live);
+                if (!live && j < n) {
+                    ray_i = base + j;
+                    const float4 ra = A[ray_i], rb = B[ray_i];
+                    lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
+                    slot = f2u(ra.w);
+                    has_ray = true;
+                    live = n_ent > 0;
+                    if (live) { a = ent[0]; b = ent[1]; }
+                }
+                next = min(n, next + n_idle);
+                continue;
+            }
+        }
+        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
+        const bool at_box = live && tag == TAG_BOX;
+        const bool at_prim = live && tag != TAG_BOX;
+        const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
+        RT_UTIL_TRIP(cnt);
+        if (at_box) {
+            if (COUNT) cnt.box++;
+            r.i = box_step(a, b, r, t_min);
+            live = r.i < n_ent;
+            if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+        }
+        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
+            if (at_prim) {
+                if (tag == TAG_TRI) {
+                    if (COUNT) cnt.tri++;
+                    const float4 c = ent[2 * r.i + 2];
+                    tri_step(a, b, c, r, t_min);
+                    r.i = r.i + 2;
+                } else {
+                    if (COUNT) cnt.sph++;
+                    sphere_step(a, b, r, t_min);
+                    r.i = r.i + 1;
+                }
+                live = r.i < n_ent;
+                if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            }
+        }
+    }
+}
+
 // Closest hit for the n live rays of the segment at `base`: terminates paths (sky, emitter, depth
 // cap) or records the hit and queues the ray under its material kind; n0 / n1 / n2 return the
 // queue lengths.  Whole wave, converged.
@@ -764,9 +862,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             enqueue(ka, ia);
             enqueue(kb, ib);
         }
+    } else if (SWEEP == 5 || SWEEP == 6) {
+        walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.units, sc.n_units, sc.prim_wait,
+                            sc.refill, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
+                            sky_intensity, n0, n1, n2, cnt);
     } else {
-        // (Tried and measured slower on the 1-k-entry scenes: refilling idle lanes with the next
-        // rays of the segment.)
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
             const bool valid = j0 + lane < n;
@@ -986,6 +1086,7 @@ struct PathBuffers {
     uint32_t *q0, *q1, *q2;
     float4* Lbuf;
     uint32_t* segcnt;          // [max_bounces * n_seg]: live rays entering each depth (ray totals)
+    Totals* totals;            // visit counters (diagnostic builds)
 };
 
 __device__ __forceinline__ void stage_fence() {
@@ -1001,13 +1102,13 @@ __device__ __forceinline__ void stage_fence() {
 #define RT_LDS_BLOCK 512
 #endif
 template <int SWEEP>
-__global__ void __launch_bounds__(SWEEP == 4 ? RT_LDS_BLOCK : RT_WAVE)
+__global__ void __launch_bounds__(SWEEP == 4 || SWEEP == 6 ? RT_LDS_BLOCK : RT_WAVE)
     __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
        uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
-    const uint32_t wpb = SWEEP == 4 ? RT_LDS_BLOCK / 64 : RT_WPB;
+    const uint32_t wpb = SWEEP == 4 || SWEEP == 6 ? RT_LDS_BLOCK / 64 : RT_WPB;
     const uint32_t seg = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (SWEEP == 4) {
+    if (SWEEP == 4 || SWEEP == 6) {
         const float4* src = (const float4*)sc.units;
         float4* dst = (float4*)lds_stack;
         for (uint32_t i = threadIdx.x; i < 2u * sc.n_units; i += RT_LDS_BLOCK) dst[i] = src[i];
@@ -1029,14 +1130,24 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
         const bool last = d + 1u == max_bounces;
         stage_fence();
         uint32_t n0, n1, n2;
+#ifdef RT_UTIL
+        trace_segment<true, SWEEP>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
+                                   t_min, sky_intensity, n0, n1, n2, cnt);
+#else
         trace_segment<false, SWEEP>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
                                     t_min, sky_intensity, n0, n1, n2, cnt);
+#endif
         if (last) break;
         stage_fence();
         n = shade_segment(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, nA, nB, nC, pb.Lbuf, base, n0, n1, n2, d, lane);
     }
 #ifdef RT_STAMPS
     if (lane == 0) write_stamp(stamp_slot, seg, stamp_t0, n);
+#endif
+#ifdef RT_UTIL
+    atomicAdd(&pb.totals->box, (unsigned long long)cnt.box);
+    atomicAdd(&pb.totals->tri, (unsigned long long)cnt.tri);
+    atomicAdd(&pb.totals->sph, (unsigned long long)cnt.sph);
 #endif
 }
 
@@ -1156,6 +1267,7 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
     pb.q0 = rb.queue[0]; pb.q1 = rb.queue[1]; pb.q2 = rb.queue[2];
     pb.Lbuf = (float4*)rb.Lbuf;
     pb.segcnt = rb.segcnt;
+    pb.totals = rb.totals;
     const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
 #ifdef RT_STAMPS
     static uint32_t stamped = 0;
@@ -1166,13 +1278,17 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
     if (sc.lds_walk && !sc.ordered && !sc.sweep) {
         const size_t bytes = (size_t)sc.n_units * 32u;
-        hipLaunchKernelGGL((k_path<4>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK),
-                           bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min,
-                           sky_intensity RT_STAMP_ARG);
+#define RT_PATH_LDS(SWP)                                                                                \
+        hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
+                           bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
+                           sky_intensity RT_STAMP_ARG)
+        if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
+#undef RT_PATH_LDS
         return check_launch();
     }
-    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
-    if (mode == 3) RT_PATH(3);
+    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : (sc.refill ? 5 : 0));
+    if (mode == 5) RT_PATH(5);
+    else if (mode == 3) RT_PATH(3);
     else if (mode == 2) RT_PATH(2);
     else if (mode == 1) RT_PATH(1);
     else RT_PATH(0);

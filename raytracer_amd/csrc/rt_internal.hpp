@@ -99,6 +99,7 @@ struct DevScene {
     uint32_t ordered;         // 1: near-child-first walk with a per-lane stack (not the reference's visiting order)
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
     uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
+    uint32_t refill;          // per-lane walk in the fused kernel: idle lanes that trigger a refill from the segment (0: off)
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

@@ -208,6 +208,37 @@ def test_one_kernel_per_batch_equals_staged_launches(rt, ob, ctx):
         assert np.array_equal(fused.view(np.uint32), staged.view(np.uint32))
 
 
+def test_refilled_walk_renders_the_same_frame(rt, ob, ctx, monkeypatch):
+    """The per-lane walk that hands idle lanes the next rays of the segment (chosen by the first
+    render's timing on big scenes; forced here through RT_REFILL, which a scene reads when it is
+    committed) changes which lane walks a ray and when, nothing else: the frame must equal the
+    staged frame bit for bit, from memory (cornell_box.obj) and out of LDS (thing.obj), with long
+    segments (one batch) and short ones (several batches), on the reference and the SAH tree."""
+    for osc, size, spp in ((ob.Scene.cornell_box(asset("cornell_box.obj")), (96, 80), 48),
+                           (ob.Scene.world2(asset("thing.obj"), 1), (64, 48), 24)):
+        w, h = size
+        cam = product_camera(rt, osc, w, h)
+        for build in (rt.BUILD_REFERENCE, rt.BUILD_SAH):
+            monkeypatch.delenv("RT_REFILL", raising=False)
+            plain = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=build)
+            plain.set_traversal(rt.TRAVERSAL_PER_LANE)
+            scenes = []
+            for refill in ("8", "40"):
+                monkeypatch.setenv("RT_REFILL", refill)
+                sc = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=build)
+                sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+                scenes.append(sc)
+            # (a pixel's samples are summed batch by batch, so frames are compared at equal batching)
+            for max_paths in (0, w * h * 7):
+                staged, st0 = plain.render(cam, rt.Scene.params(w, h, spp, 8, osc.sky, max_paths=max_paths,
+                                                                flags=rt.RENDER_STAGED))
+                for sc in scenes:
+                    img, st = sc.render(cam, rt.Scene.params(w, h, spp, 8, osc.sky, max_paths=max_paths))
+                    assert st["rays_traced"] == st0["rays_traced"]
+                    assert np.array_equal(img.view(np.uint32), staged.view(np.uint32))
+    monkeypatch.delenv("RT_REFILL", raising=False)
+
+
 def test_progressive_render_delivers_the_reference_block_events(rt, ob, ctx):
     """rt_world_render_progressive: steps 10, 20, 40, 50 of a 50-spp frame; after each, every 64x64
     block (edge blocks clipped) in j-then-i order, tonemapped with the samples so far, with red

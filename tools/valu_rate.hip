@@ -10,7 +10,7 @@
 constexpr int ITERS = 4096;    // x 64 instructions per iteration
 
 template <int KIND>
-__global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk, float seed) {
+__global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk, float seed, const float* tab) {
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     float b0 = a0 * 0.5f, b1 = a1 * 0.5f, b2 = a2 * 0.5f, b3 = a3 * 0.5f, b4 = a4 * 0.5f, b5 = a5 * 0.5f, b6 = a6 * 0.5f, b7 = a7 * 0.5f;
     const float m = 1.0000001f;
@@ -70,6 +70,32 @@ __global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk
                               "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n"
                               "v_cndmask_b32_e64 %0, %0, %4, s[20:21]\n v_cndmask_b32_e64 %2, %2, %4, s[24:25]"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");)
+        } else if (KIND == 11 || KIND == 13) { // s_load_dwordx16 (KIND 13: x8) of a 4 KB table, two loads in flight per wave
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            typedef float f8v __attribute__((ext_vector_type(8)));
+            for (int r = 0; r < 32; r++) {
+                const unsigned off0 = ((i * 64 + r * 2) & 63) * 64, off1 = ((i * 64 + r * 2 + 1) & 63) * 64;
+                if (KIND == 11) {
+                    f16v e0, e1;
+                    asm volatile("s_load_dwordx16 %0, %2, %3\n s_load_dwordx16 %1, %2, %4\n s_waitcnt lgkmcnt(0)"
+                                 : "=&s"(e0), "=&s"(e1) : "s"(tab), "s"(off0), "s"(off1) : "memory");
+                    a0 += e0[0] + e1[15];
+                } else {
+                    f8v e0, e1;
+                    asm volatile("s_load_dwordx8 %0, %2, %3\n s_load_dwordx8 %1, %2, %4\n s_waitcnt lgkmcnt(0)"
+                                 : "=&s"(e0), "=&s"(e1) : "s"(tab), "s"(off0), "s"(off1) : "memory");
+                    a0 += e0[0] + e1[7];
+                }
+            }
+        } else if (KIND == 12 || KIND == 14) { // the sweep's mix: one s_load_dwordx16 issued ahead of 64 v_fma_f32 (KIND 14: no load)
+            typedef float f16v __attribute__((ext_vector_type(16)));
+            f16v e0;
+            const unsigned off0 = (i & 63) * 64;
+            if (KIND == 12) asm volatile("s_load_dwordx16 %0, %1, %2" : "=&s"(e0) : "s"(tab), "s"(off0) : "memory");
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+            if (KIND == 12) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e0)); a1 += e0[3]; }
         } else if (KIND == 5) {  // v_pk_mul_f32 with one scalar-register operand pair
             typedef float f2 __attribute__((ext_vector_type(2)));
             f2 p0 = {a0, b0}, p1 = {a1, b1}, p2 = {a2, b2}, p3 = {a3, b3}, p4 = {a4, b4}, p5 = {a5, b5}, p6 = {a6, b6}, p7 = {a7, b7};
@@ -87,20 +113,26 @@ __global__ void __launch_bounds__(64) k_rate(float* out, unsigned long long* clk
 }
 
 template <int KIND>
-static void run(const char* name, int simds, float* out, unsigned long long* clk) {
+static void run(const char* name, int simds, float* out, unsigned long long* clk, const float* tab = nullptr) {
     for (int w : {1, 2, 4, 8}) {
         const int blocks = simds * w;
-        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f);   // warm
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f, tab);   // warm
         hipDeviceSynchronize();
-        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f);
+        hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, out, clk, 1.0f, tab);
         hipDeviceSynchronize();
         static unsigned long long h[2 * 8192];
         hipMemcpy(h, clk, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost);
         double cyc = 0, real = 0;
         for (int b = 0; b < blocks; b++) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
         cyc /= blocks; real /= blocks;
-        const double per_rep = KIND == 9 ? 10.0 : 8.0;    // instructions in one of the 8 repeats
+        const double per_rep = KIND == 9 ? 10.0 : 8.0;    // instructions in one of the 8 repeats (loads: 64 per iteration)
         const double n_inst = (double)ITERS * 8 * per_rep;
+        if (KIND == 11 || KIND == 13) {
+            const double bytes = (double)ITERS * 64 * (KIND == 11 ? 64 : 32);
+            printf("%-28s waves/SIMD %d: %.1f cycles per load per wave, %.2f bytes per cycle per CU\n", name, w, cyc / (ITERS * 64.0),
+                   bytes * 4 * w / cyc);
+            continue;
+        }
         printf("%-28s waves/SIMD %d: %.2f cycles per instruction per wave, %.2f SIMD cycles per instruction, clock %.2f GHz\n",
                name, w, cyc / n_inst, cyc / n_inst / w, cyc / real * 0.1);
     }
@@ -124,5 +156,12 @@ int main() {
     run<8>("v_cmp->sgpr->v_cndmask", simds, out, clk);
     run<9>("8 v_fma + cmp + branch", simds, out, clk);
     run<10>("v_cmp->s_and->v_cndmask", simds, out, clk);
+    float* tab;
+    hipMalloc(&tab, 4096 + 64);
+    hipMemset(tab, 0, 4096 + 64);
+    run<11>("s_load_dwordx16 (4 KB table)", simds, out, clk, tab);
+    run<13>("s_load_dwordx8 (4 KB table)", simds, out, clk, tab);
+    run<14>("64 v_fma per iteration", simds, out, clk, tab);
+    run<12>("64 v_fma + 1 s_load_dwordx16", simds, out, clk, tab);
     return 0;
 }
