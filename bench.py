@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even for one rank")
     ap.add_argument("--max-paths", type=int, default=0)
-    ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered"], default="auto")
+    ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered", "octant"], default="auto")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env(args.backend or None, force=args.force_dist)
@@ -165,7 +165,8 @@ def main():
     wld = make_world(ctx, kind)
     build_s = time.time() - t0
     wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
-                             "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED}[args.traversal])
+                             "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,
+                             "octant": rt.TRAVERSAL_OCTANT}[args.traversal])
     cam = wld.camera(width, height)
     bands, samples = partition(width, height, spp, world, rank)
     if args.emulate:

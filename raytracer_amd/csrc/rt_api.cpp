@@ -114,7 +114,7 @@ struct rt_scene {
     uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
     bool committed = false;
     FlatScene flat;
-    DeviceBuffer d_entries, d_units, d_geo, d_meta, d_mats;
+    DeviceBuffer d_entries, d_units, d_units_oct, d_geo, d_meta, d_mats;
     DevScene dev{};
 };
 
@@ -301,10 +301,28 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
 static int apply_traversal(rt_scene* s, int mode) {
     if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
+    if (mode == RT_TRAVERSAL_OCTANT) {
+        if (!s->ordered_ok)
+            return fail(RT_ERR_UNSUPPORTED, "octant traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
+        if ((uint64_t)s->dev.n_units * 8u > SKIP_MASK)
+            return fail(RT_ERR_UNSUPPORTED, "octant traversal: eight copies of the trees exceed the 30-bit links");
+        if (!s->ctx) return fail(RT_ERR_DEVICE, "octant traversal needs a device context");
+        if (!s->d_units_oct.p && s->dev.n_units) {   // first use: the eight copies, from the device's unit array
+            int rc = set_device(s->ctx);
+            if (rc) return rc;
+            std::vector<uint32_t> units((size_t)s->dev.n_units * 8), oct;
+            HIP_TRY(hipMemcpy(units.data(), s->d_units.p, units.size() * 4, hipMemcpyDeviceToHost));
+            build_octant_units(units.data(), s->dev.n_units, oct);
+            HIP_TRY(s->d_units_oct.ensure(oct.size() * 4));
+            HIP_TRY(hipMemcpy(s->d_units_oct.p, oct.data(), oct.size() * 4, hipMemcpyHostToDevice));
+        }
+        s->dev.units_oct = s->d_units_oct.p;
+    }
+    s->dev.octant = mode == RT_TRAVERSAL_OCTANT ? 1u : 0u;
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
     s->auto_tuned = false;
     s->dev.refill = s->env_refill;
-    s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : (s->dev.lds_walk ? 4u : 8u);
+    s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : (s->dev.lds_walk && !s->dev.octant ? 4u : 8u);
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     return RT_OK;
@@ -326,7 +344,7 @@ int rt_scene_set_build(rt_scene* s, int build_mode) {
 
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
-    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_ORDERED) return fail(RT_ERR_INVALID, "unknown traversal mode");
+    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_OCTANT) return fail(RT_ERR_INVALID, "unknown traversal mode");
     if (s->committed) {
         int rc = apply_traversal(s, mode);
         if (rc) return rc;
@@ -551,7 +569,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     auto form_target = [&](const DevScene& d) -> uint32_t {
         if (d.sweep) return ctx->wave_target_sweep;
         if (std::getenv("RT_WAVE_TARGET") || d.ordered || staged) return ctx->wave_target;
-        if (d.lds_walk) return ctx->wave_target / 4;   // 8-wave workgroups even out less finely
+        if (d.lds_walk && !d.octant) return ctx->wave_target / 4;   // 8-wave workgroups even out less finely
         return d.refill ? ctx->wave_target / 2 : ctx->wave_target;   // refill wants long segments
     };
     auto seg_len_for = [&](size_t n_slots, uint32_t target) -> uint32_t {
@@ -562,7 +580,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         const uint32_t wait_mem = s->env_prim_wait ? s->env_prim_wait : 8u, wait_refill = s->env_prim_wait ? s->env_prim_wait : 16u;
         if (s->traversal == RT_TRAVERSAL_AUTO && s->dev.sweep && s->dev.lds_walk)
             forms = {Form{1u, 0u, s->dev.prim_wait}, Form{0u, 0u, s->dev.prim_wait}};
-        else if (!s->dev.sweep && !s->dev.lds_walk && !std::getenv("RT_REFILL"))
+        else if (!s->dev.sweep && (!s->dev.lds_walk || s->dev.octant) && !std::getenv("RT_REFILL"))
             forms = {Form{0u, 0u, wait_mem}, Form{0u, 16u, wait_refill}};
         size_t best = 0;
         float best_ms = 0.0f;

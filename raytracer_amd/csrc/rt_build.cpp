@@ -381,6 +381,58 @@ void pack_units(FlatScene& out) {
 
 }  // namespace
 
+namespace {
+// one octant's copy of the unit array (build_octant_units)
+struct OctantCopy {
+    const uint32_t* src;       // the reference-order units, as words
+    uint32_t* dst;             // this octant's copy
+    uint32_t base;             // first unit of the copy in the whole array
+    uint32_t oct;
+
+    uint32_t tag(uint32_t u) const { return src[(size_t)u * 8 + 3] >> TAG_SHIFT; }
+    uint32_t end_of(uint32_t u) const {
+        const uint32_t t = tag(u);
+        return t == TAG_BOX ? (src[(size_t)u * 8 + 3] & SKIP_MASK) : u + (t == TAG_TRI ? 2u : 1u);
+    }
+    // copies the subtree at unit `u` to position `at` of the copy; returns the position behind it
+    uint32_t emit(uint32_t u, uint32_t at) {
+        if (tag(u) != TAG_BOX) {
+            const uint32_t n = end_of(u) - u;
+            std::memcpy(dst + (size_t)at * 8, src + (size_t)u * 8, (size_t)n * 32);
+            return at + n;
+        }
+        std::memcpy(dst + (size_t)at * 8, src + (size_t)u * 8, 32);
+        const uint32_t end = end_of(u), link = src[(size_t)u * 8 + 7];
+        uint32_t pos = at + 1;
+        const uint32_t second = link & ORD_RIGHT_MASK;
+        if (second != 0u) {
+            const uint32_t axis = (link >> ORD_AXIS_SHIFT) & 3u;
+            const bool dir_positive = ((oct >> axis) & 1u) == 0u;
+            const bool first_is_near = dir_positive == ((link & ORD_FIRST_LOWER) != 0u);
+            pos = emit(first_is_near ? u + 1 : second, pos);
+            pos = emit(first_is_near ? second : u + 1, pos);
+        } else {
+            for (uint32_t c = u + 1; c < end; c = end_of(c)) pos = emit(c, pos);
+        }
+        dst[(size_t)at * 8 + 3] = (TAG_BOX << TAG_SHIFT) | (base + pos);
+        dst[(size_t)at * 8 + 7] = 0u;
+        return pos;
+    }
+};
+}  // namespace
+
+void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out) {
+    out.assign(n_units * 8 * 8, 0u);
+    std::vector<std::thread> workers;
+    for (uint32_t oct = 0; oct < 8; oct++)
+        workers.emplace_back([=, &out]() {
+            OctantCopy c{units, out.data() + (size_t)oct * n_units * 8, (uint32_t)(oct * n_units), oct};
+            uint32_t pos = 0;
+            for (uint32_t u = 0; u < n_units; u = c.end_of(u)) pos = c.emit(u, pos);   // top-level entries in order
+        });
+    for (std::thread& w : workers) w.join();
+}
+
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
                              int root_kind, int build_mode, FlatScene& out) {
     out = FlatScene();

@@ -146,16 +146,25 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
 // there while boxes remain to be tested by other lanes, until prim_wait lanes stand at
 // primitives (or no lane stands at a box): the long primitive routines then run with many lanes
 // instead of once per loop trip for a few.
-template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent, uint32_t prim_wait,
+// OCT (opt-in, not the reference's visiting order): `ent` holds eight copies of the n_ent units,
+// one per direction octant, each in the pre-order that puts the nearer child of every box first
+// for that octant's rays (links count from the start of the whole array); the lane walks the copy
+// of its ray's octant.
+__device__ __forceinline__ uint32_t octant_of(float dx, float dy, float dz) {
+    return (dx >= 0.0f ? 0u : 1u) | (dy >= 0.0f ? 0u : 2u) | (dz >= 0.0f ? 0u : 4u);
+}
+template <bool COUNT, bool OCT = false>
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                             bool valid, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
-    bool live = valid && n_ent > 0;
+    bool live = valid && n_ent_ > 0;
+    uint32_t n_ent = n_ent_;                   // OCT: the end of the lane's copy
+    if (OCT) { r.i = n_ent_ * octant_of(dx, dy, dz); n_ent = r.i + n_ent_; }
     float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
-    if (live) { a = ent[0]; b = ent[1]; }
+    if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
     for (;;) {
         const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
         const bool at_box = live && tag == TAG_BOX;
@@ -502,7 +511,9 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
 extern __shared__ uint32_t lds_stack[];
 
 // SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene),
-//        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only)
+//        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
+//        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
+//        8 = 7 with idle lanes refilled (k_path only)
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -544,6 +555,8 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
                 closest_hit_ordered<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait,
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, threadIdx.x & 63u,
                                            valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            else if (SWEEP == 7)
+                closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
@@ -737,8 +750,8 @@ __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 // (finish_ray + queueing) and take the next rays of the segment.  Every ray is still walked by one
 // lane in the reference's order; only which lane and when changes, and nothing downstream depends
 // on that (queues are compacted per kind, radiance is stored per path slot).
-template <bool COUNT>
-__device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent, uint32_t prim_wait,
+template <bool COUNT, bool OCT = false>
+__device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                              uint32_t refill_min, const float4* __restrict__ mats,
                                              const uint32_t* __restrict__ prim_meta, const float4* __restrict__ A,
                                              const float4* __restrict__ B, const float4* __restrict__ C,
@@ -750,6 +763,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     LaneRay r;
     lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
+    uint32_t n_ent = n_ent_;                   // OCT: the end of the copy the lane's ray walks
     bool has_ray = false, live = false;
     uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
     float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
@@ -780,8 +794,9 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
                     slot = f2u(ra.w);
                     has_ray = true;
-                    live = n_ent > 0;
-                    if (live) { a = ent[0]; b = ent[1]; }
+                    live = n_ent_ > 0;
+                    if (OCT) { r.i = n_ent_ * octant_of(rb.x, rb.y, rb.z); n_ent = r.i + n_ent_; }
+                    if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
                 }
                 next = min(n, next + n_idle);
                 continue;
@@ -866,6 +881,10 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
         walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.units, sc.n_units, sc.prim_wait,
                             sc.refill, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
                             sky_intensity, n0, n1, n2, cnt);
+    } else if (SWEEP == 8) {
+        walk_segment<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, mats, sc.prim_meta,
+                                  A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1,
+                                  n2, cnt);
     } else {
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
@@ -881,6 +900,8 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                            a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 4)
                 closest_hit<COUNT>((const float4*)lds_stack, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 7)
+                closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
@@ -1217,8 +1238,9 @@ int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_ray
 #define RT_TRACE_API(CNT, SWP)                                                                          \
     hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), lds, st, sc, (const float*)d_rays, n, \
                        t_min, t_max, (rt_hit*)d_hits, d_counts)
-    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
-    if (mode == 3) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
+    const int mode = sc.octant ? 7 : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0));
+    if (mode == 7) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
+    else if (mode == 3) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
     else if (mode == 2) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
     else if (mode == 1) { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
@@ -1248,8 +1270,9 @@ int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, c
     static uint32_t stamped_launches = 0;
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0);
-    if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
+    const int mode = sc.octant ? 7 : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0));
+    if (mode == 7) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
+    else if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
     else if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
     else if (mode == 1) { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
@@ -1276,7 +1299,7 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
 #define RT_PATH(SWP)                                                                                    \
     hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
-    if (sc.lds_walk && !sc.ordered && !sc.sweep) {
+    if (sc.lds_walk && !sc.ordered && !sc.sweep && !sc.octant) {
         const size_t bytes = (size_t)sc.n_units * 32u;
 #define RT_PATH_LDS(SWP)                                                                                \
         hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
@@ -1286,8 +1309,11 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
 #undef RT_PATH_LDS
         return check_launch();
     }
-    const int mode = sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : (sc.refill ? 5 : 0));
-    if (mode == 5) RT_PATH(5);
+    const int mode = sc.octant ? (sc.refill ? 8 : 7)
+                               : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : (sc.refill ? 5 : 0)));
+    if (mode == 8) RT_PATH(8);
+    else if (mode == 7) RT_PATH(7);
+    else if (mode == 5) RT_PATH(5);
     else if (mode == 3) RT_PATH(3);
     else if (mode == 2) RT_PATH(2);
     else if (mode == 1) RT_PATH(1);

@@ -79,6 +79,13 @@ struct SceneObject {
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
                              int root_kind, int build_mode, FlatScene& out);
 
+// The unit array once per direction octant (bit k of the octant: the ray's direction is negative
+// along axis k), copy o at units [o * n_units, (o + 1) * n_units) with links that count from the
+// start of the whole array: in copy o the two children of every box are stored nearer child first
+// for the rays of that octant (by the axis and order annotate_children recorded), so the plain
+// skip-link walk meets them front to back.  `units` must carry the child links (ordered_ok).
+void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out);   // units as 32-bit words
+
 // ---------------------------------------------------------------------------------------------
 // Device side
 // ---------------------------------------------------------------------------------------------
@@ -100,6 +107,8 @@ struct DevScene {
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
     uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
     uint32_t refill;          // per-lane walk in the fused kernel: idle lanes that trigger a refill from the segment (0: off)
+    const void* units_oct;    // float4[8 * 2 * n_units]: the unit array once per direction octant (octant walk)
+    uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

@@ -1,7 +1,8 @@
-"""The opt-in ordered walk (RT_TRAVERSAL_ORDERED) against the oracle.
+"""The opt-in near-child-first walks (RT_TRAVERSAL_ORDERED: per-lane stack; RT_TRAVERSAL_OCTANT: one
+pre-ordered copy of the trees per direction octant, no stack) against the oracle.
 
-It runs the reference's box and primitive tests on the reference's trees but visits the nearer
-child first, so it is not the reference's visiting order.  The closest hit must still be the
+Both run the reference's box and primitive tests on the reference's trees but visits the nearer
+child first, so theirs is not the reference's visiting order.  The closest hit must still be the
 oracle's: same hit/miss, bit-identical t, and the same primitive unless two primitives tie in t.
 t, the hit point and hit/miss must match on every ray.  The primitive may differ where two
 primitives tie in t, which real scenes do produce (a ray through the shared diagonal of a wall's
@@ -16,8 +17,13 @@ from helpers import asset, mirror, random_rays, random_scene
 pytestmark = pytest.mark.gpu
 
 
-def _ordered_vs_oracle(rt, sc, rays, want, t_min=0.001, t_max=np.inf, same_prim=True):
-    sc.set_traversal(rt.TRAVERSAL_ORDERED)
+@pytest.fixture(params=["ordered", "octant"])
+def walk(request, rt):
+    return {"ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT}[request.param]
+
+
+def _ordered_vs_oracle(rt, sc, walk, rays, want, t_min=0.001, t_max=np.inf, same_prim=True):
+    sc.set_traversal(walk)
     got = sc.trace(rays, t_min, t_max)
     sc.set_traversal(rt.TRAVERSAL_AUTO)
     miss_g, miss_w = got["prim_id"] == rt.MISS, want["prim_id"] == rt.MISS
@@ -36,34 +42,34 @@ def _ordered_vs_oracle(rt, sc, rays, want, t_min=0.001, t_max=np.inf, same_prim=
 
 
 @pytest.mark.parametrize("name", ["cornell_box_plane.obj", "cornell_box.obj"])
-def test_cornell(rt, ob, ctx, name):
+def test_cornell(rt, ob, ctx, walk, name):
     osc = ob.Scene.cornell_box(asset(name))
     sc = mirror(rt, ctx, osc)
     rays = osc.record_rays(96, 96, 4, 8, cap=200000, stride=1)
     want, _ = osc.trace(rays)
-    _ordered_vs_oracle(rt, sc, rays, want)
+    _ordered_vs_oracle(rt, sc, walk, rays, want)
 
 
-def test_world1_and_world2(rt, ob, ctx):
+def test_world1_and_world2(rt, ob, ctx, walk):
     for osc in (ob.Scene.world1(), ob.Scene.world2(asset("thing.obj"), 1)):
         sc = mirror(rt, ctx, osc)
         rays = osc.record_rays(128, 96, 4, 6, cap=200000)
         want, _ = osc.trace(rays)
-        _ordered_vs_oracle(rt, sc, rays, want)
+        _ordered_vs_oracle(rt, sc, walk, rays, want)
 
 
 @pytest.mark.parametrize("root", [0, 2])
-def test_random_scenes_and_ranges(rt, ob, ctx, root):
+def test_random_scenes_and_ranges(rt, ob, ctx, walk, root):
     mats, objects, _ = random_scene(ob, 3, n_spheres=51, n_meshes=3, tris_per_mesh=150)
     osc = ob.Scene.from_description(mats, objects, root)
     sc = rt.Scene(ctx, mats, objects, root)
     rays = random_rays(ob, 13, 150000, -12.0, 12.0)
     for t_min, t_max in [(0.001, np.inf), (0.05, 1.0)]:
         want, _ = osc.trace(rays, t_min, t_max)
-        _ordered_vs_oracle(rt, sc, rays, want, t_min, t_max)
+        _ordered_vs_oracle(rt, sc, walk, rays, want, t_min, t_max)
 
 
-def test_degenerate_scenes(rt, ob, ctx):
+def test_degenerate_scenes(rt, ob, ctx, walk):
     from helpers import random_mesh
     mats, _, _ = random_scene(ob, 5)
     rays = random_rays(ob, 1, 5000, -3.0, 3.0)
@@ -78,10 +84,10 @@ def test_degenerate_scenes(rt, ob, ctx):
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
         want, _ = osc.trace(rays)
-        _ordered_vs_oracle(rt, sc, rays, want)
+        _ordered_vs_oracle(rt, sc, walk, rays, want)
 
 
-def test_coincident_primitives_keep_t(rt, ob, ctx):
+def test_coincident_primitives_keep_t(rt, ob, ctx, walk):
     from helpers import random_mesh
     mats, _, _ = random_scene(ob, 5)
     rng = np.random.default_rng(4)
@@ -92,10 +98,10 @@ def test_coincident_primitives_keep_t(rt, ob, ctx):
     sc = rt.Scene(ctx, mats, [("mesh", dup)], ob.ROOT_SINGLE)
     rays = random_rays(ob, 2, 100000, -4.0, 4.0)
     want, _ = osc.trace(rays)
-    _ordered_vs_oracle(rt, sc, rays, want, same_prim=False)
+    _ordered_vs_oracle(rt, sc, walk, rays, want, same_prim=False)
 
 
-def test_fewer_visits_and_same_image(rt, ob, ctx):
+def test_fewer_visits_and_same_image(rt, ob, ctx, monkeypatch):
     """Never more box tests per ray than the reference order (how many fewer depends on the
     scene: the upper boxes of cornell_box.obj all span the room and cannot be culled in any
     order); and a rendered frame that matches the reference-order frame (same RNG keys, so
@@ -108,9 +114,15 @@ def test_fewer_visits_and_same_image(rt, ob, ctx):
     d_hits = torch.zeros(len(rays) * 10, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     counts = {}
-    for mode in (rt.TRAVERSAL_PER_LANE, rt.TRAVERSAL_ORDERED):
+    hits = {}
+    for mode in (rt.TRAVERSAL_PER_LANE, rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT):
         sc.set_traversal(mode)
         counts[mode] = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
+        hits[mode] = d_hits.cpu().numpy().copy()
+    # the octant copies encode the very choice the ordered walk makes at every box: the same visits,
+    # the same hits down to the primitive picked on a tie
+    assert counts[rt.TRAVERSAL_OCTANT] == counts[rt.TRAVERSAL_ORDERED]
+    assert np.array_equal(hits[rt.TRAVERSAL_OCTANT], hits[rt.TRAVERSAL_ORDERED])
     print("visits per ray, reference order vs ordered:",
           [round(c / len(rays), 2) for c in counts[rt.TRAVERSAL_PER_LANE]],
           [round(c / len(rays), 2) for c in counts[rt.TRAVERSAL_ORDERED]])
@@ -122,9 +134,19 @@ def test_fewer_visits_and_same_image(rt, ob, ctx):
     ref, st_ref = sc.render(cam, p)
     sc.set_traversal(rt.TRAVERSAL_ORDERED)
     img, st = sc.render(cam, p)
-    sc.set_traversal(rt.TRAVERSAL_AUTO)
     # a tie resolved the other way changes that path only
     assert abs(st["rays_traced"] - st_ref["rays_traced"]) <= 1e-4 * st_ref["rays_traced"]
     differing = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).mean()
     print(f"pixels that differ between the two visiting orders: {differing:.2e}")
     assert differing <= 1e-3
+    # the octant walk, plain and with idle lanes refilled (the scene's first render times both):
+    # the ordered walk's frame bit for bit
+    sc.set_traversal(rt.TRAVERSAL_AUTO)
+    for refill in ("0", "16"):                 # (read when a scene is committed and when it renders)
+        monkeypatch.setenv("RT_REFILL", refill)
+        sc8 = mirror(rt, ctx, osc)
+        sc8.set_traversal(rt.TRAVERSAL_OCTANT)
+        img8, st8 = sc8.render(cam, p)
+        assert st8["rays_traced"] == st["rays_traced"]
+        assert np.array_equal(img8.view(np.uint32), img.view(np.uint32))
+    monkeypatch.delenv("RT_REFILL", raising=False)
