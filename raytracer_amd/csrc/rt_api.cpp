@@ -166,6 +166,9 @@ int get_events(Pipe& pp, size_t n) {
 // paths in flight over both pipelines: ~132 B of wavefront state each (8.4 GB of the 288 GB);
 // long launches amortise the tail in which the last waves of a kernel run alone
 constexpr size_t DEFAULT_MAX_PATHS = 64u << 20;
+#ifndef RT_SPLIT_MI
+#define RT_SPLIT_MI 16
+#endif
 
 }  // namespace
 
@@ -543,7 +546,17 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         (uint32_t)std::min<size_t>(n_samples, std::max<size_t>(1, max_paths / (tiles_per_batch * 64)));
     size_t n_batches = ((n_tiles + tiles_per_batch - 1) / tiles_per_batch) *
                        ((n_samples + samples_per_batch - 1) / samples_per_batch);
-    const int n_pipes = (int)std::min<size_t>(n_batches, (size_t)ctx->n_pipes);
+    int n_pipes = (int)std::min<size_t>(n_batches, (size_t)ctx->n_pipes);
+    // A job that fits one batch but is big enough for several chip-filling ones is cut up as well
+    // when it is traced with the sweep or out of LDS: two kernels in flight hide each other's drain
+    // (1024^2 x 64 spp Cornell box +24 %, world1 at 16 spp +13 %).  Not the walk from memory: its
+    // refilled form lives on long segments (cornell_box.obj at 256 spp: -30 % when cut up).
+    if (s->dev.sweep || (s->dev.lds_walk && !s->dev.octant && !s->dev.ordered)) {
+        const char* e = std::getenv("RT_SPLIT_MI");        // experiments: the threshold in Mi paths (0: never)
+        const size_t split_mi = e ? (size_t)std::max(0, std::atoi(e)) : (size_t)RT_SPLIT_MI;
+        if (!p->max_paths_in_flight && split_mi && n_tiles * 64 * (size_t)n_samples >= (split_mi << 20))
+            n_pipes = ctx->n_pipes;
+    }
     if (n_pipes > 1) {
         max_paths = std::max<size_t>(64, max_paths / (size_t)n_pipes);
         // A small job (one rank's share of a frame) is cut into at least 8 batches as long as a

@@ -18,6 +18,7 @@ pub const RT_TRAVERSAL_AUTO: c_int = 0;
 pub const RT_TRAVERSAL_PER_LANE: c_int = 1;
 pub const RT_TRAVERSAL_SWEEP: c_int = 2;
 pub const RT_TRAVERSAL_ORDERED: c_int = 3;
+pub const RT_TRAVERSAL_OCTANT: c_int = 4;
 pub const RT_BUILD_REFERENCE: c_int = 0;
 pub const RT_BUILD_SAH: c_int = 1;
 pub const RT_RENDER_PROFILE: u32 = 1;
