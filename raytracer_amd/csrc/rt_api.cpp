@@ -597,6 +597,13 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             forms = {Form{0u, 0u, wait_mem}, Form{0u, 16u, wait_refill}};
         size_t best = 0;
         float best_ms = 0.0f;
+        // an error return from the probe leaves the scene on the form it had
+        struct Restore {
+            DevScene& d;
+            Form was;
+            bool keep = false;
+            ~Restore() { if (!keep) { d.sweep = was.sweep; d.refill = was.refill; d.prim_wait = was.prim_wait; } }
+        } restore{s->dev, Form{s->dev.sweep, s->dev.refill, s->dev.prim_wait}};
         for (size_t f = 0; f < forms.size(); f++) {
             s->dev.sweep = forms[f].sweep; s->dev.refill = forms[f].refill; s->dev.prim_wait = forms[f].prim_wait;
             BatchGeom g;
@@ -641,6 +648,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         if (!forms.empty()) {
             s->dev.sweep = forms[best].sweep; s->dev.refill = forms[best].refill; s->dev.prim_wait = forms[best].prim_wait;
         }
+        restore.keep = true;
         s->auto_tuned = true;
     }
     const uint32_t wave_target = form_target(s->dev);

@@ -300,3 +300,39 @@ def test_random_scene_image(rt, ob, ctx, root):
     cam = ((0.0, -16.0, 3.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.4, 16.0)
     osc = ob.Scene.from_description(mats, objects, root, camera=cam, sky=0.8)
     _compare(rt, ob, ctx, osc, 112, 80, 48, 8, clip=6.0)
+
+
+def test_headless_main_writes_the_library_frame(rt, ob, ctx, tmp_path):
+    """raytracer_amd/rt_render (examples/rt_render_main.cpp, plain C++ on the C ABI) renders the
+    reference's default job at a small size; its PPM must hold the pixels the same calls give
+    through the Python stub, and the progressive run (blocks after 10, 20, 40 ... samples, copied
+    into a framebuffer as the reference's event loop does) the same frame up to the last bit of
+    8-bit rounding (its samples are summed step by step)."""
+    import os
+    import subprocess
+    from helpers import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    w, h, spp, depth = 96, 80, 50, 6
+    world = rt.World.cornell_box(ctx, asset("cornell_box.obj"))
+    img, st = world.render(w, h, spp, depth)
+    want = ctx.tonemap(img, spp).reshape(h, w)
+    want_rgb = np.stack([(want >> 16) & 255, (want >> 8) & 255, want & 255], axis=-1).astype(np.uint8)
+    world.close()
+
+    def run(*extra):
+        out = tmp_path / "frame.ppm"
+        p = subprocess.run([exe, "--scene", "cornell", "--obj", asset("cornell_box.obj"), "--size", f"{w}x{h}",
+                            "--spp", str(spp), "--depth", str(depth), "--out", str(out), *extra],
+                           capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stdout + p.stderr
+        assert "Finished in" in p.stdout and f"{st['rays_traced']} rays" in p.stdout
+        raw = out.read_bytes()
+        header = f"P6\n{w} {h}\n255\n".encode()
+        assert raw.startswith(header) and len(raw) == len(header) + w * h * 3
+        return np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(h, w, 3), p.stdout
+
+    got, _ = run()
+    assert np.array_equal(got, want_rgb)
+    prog, text = run("--progressive")
+    assert "block events" in text
+    assert np.abs(prog.astype(int) - want_rgb.astype(int)).max() <= 1

@@ -428,3 +428,20 @@ def test_progressive_schedule_and_ppm(rt, tmp_path):
     assert raw[len(b"P6\n3 2\n255\n"):] == bytes([255, 0, 0, 0, 255, 0, 0, 0, 255, 0x10, 0x20, 0x30, 0, 0, 0, 255, 255, 255])
     with pytest.raises(rt.RtError):
         rt.write_ppm(tmp_path / "no_such_dir" / "f.ppm", px)
+
+
+def test_headless_main_fails_loudly_without_a_gpu(rt):
+    """examples/rt_render_main.cpp (the stand-in for the reference's main()) links the library only;
+    on a box without a GPU it must stop at rt_context_create with the library's message."""
+    import subprocess
+    import torch
+    from helpers import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "rt_render")
+    assert os.path.exists(exe), "build() compiles raytracer_amd/rt_render"
+    bad = subprocess.run([exe, "--bogus"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "unknown argument" in bad.stderr
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the render itself is covered by the GPU tests")
+    out = subprocess.run([exe, "--scene", "cornell_plane", "--obj", asset("cornell_box_plane.obj"), "--size", "32x32",
+                          "--spp", "2", "--out", os.devnull], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1 and "rt_context_create" in out.stderr
