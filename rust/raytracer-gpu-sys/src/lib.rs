@@ -80,20 +80,38 @@ extern "C" {
     pub fn rt_scene_commit(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_num_prims(scene: *const rt_scene) -> usize;
     pub fn rt_scene_num_entries(scene: *const rt_scene) -> usize;
+    pub fn rt_scene_get_entries(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_scene_num_units(scene: *const rt_scene) -> usize;
+    pub fn rt_scene_get_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
 
     pub fn rt_trace(scene: *mut rt_scene, rays: *const rt_ray, n: usize, t_min: f32, t_max: f32, out: *mut rt_hit) -> c_int;
+    pub fn rt_trace_device(scene: *mut rt_scene, d_rays: *const c_void, n: usize, t_min: f32, t_max: f32,
+                           d_hits: *mut c_void, counts: *mut u64) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
                      accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
                             d_accum_rgb: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap(ctx: *mut rt_context, accum_rgb: *const f32, spp: u32, out_0rgb: *mut u32, npix: usize) -> c_int;
+    pub fn rt_tonemap_device(ctx: *mut rt_context, d_accum_rgb: *const c_void, spp: u32, d_out_0rgb: *mut c_void,
+                             npix: usize) -> c_int;
 
     pub fn rt_camera_setup(look_from: *const f32, look_at: *const f32, vup: *const f32, vfov: f32, aperture: f32,
                            focus_dist: f32, aspect_ratio: f32, out: *mut rt_camera) -> c_int;
     pub fn rt_world_create_world1(ctx: *mut rt_context, out: *mut *mut rt_world) -> c_int;
     pub fn rt_world_create_world2(ctx: *mut rt_context, thing_obj: *const c_char, variant: c_int, out: *mut *mut rt_world) -> c_int;
     pub fn rt_world_create_cornell_box(ctx: *mut rt_context, obj_path: *const c_char, out: *mut *mut rt_world) -> c_int;
+    pub fn rt_world_create_soup(ctx: *mut rt_context, n_tris: u64, grid: u32, seed: u32, out: *mut *mut rt_world) -> c_int;
     pub fn rt_world_destroy(world: *mut rt_world);
+    pub fn rt_world_scene(world: *mut rt_world) -> *mut rt_scene;
+    pub fn rt_world_sky_intensity(world: *const rt_world) -> f32;
+    pub fn rt_world_camera(world: *const rt_world, aspect_ratio: f32, out: *mut rt_camera) -> c_int;
+    pub fn rt_world_num_materials(world: *const rt_world) -> usize;
+    pub fn rt_world_get_materials(world: *const rt_world, out: *mut rt_material) -> c_int;
+    pub fn rt_world_num_objects(world: *const rt_world) -> usize;
+    pub fn rt_world_object_info(world: *const rt_world, i: usize, count: *mut usize) -> c_int;
+    pub fn rt_world_get_sphere(world: *const rt_world, i: usize, out: *mut rt_sphere) -> c_int;
+    pub fn rt_world_get_mesh(world: *const rt_world, i: usize, out: *mut rt_triangle) -> c_int;
+    pub fn rt_world_root_kind(world: *const rt_world) -> c_int;
     pub fn rt_world_render(world: *mut rt_world, width: u32, height: u32, spp: u32, max_bounces: u32, seed: u64,
                            accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_world_render_progressive(world: *mut rt_world, width: u32, height: u32, spp: u32, max_bounces: u32,
@@ -101,6 +119,7 @@ extern "C" {
                                        stats: *mut rt_stats) -> c_int;
     pub fn rt_progressive_schedule(spp: u32, counts: *mut u32, cap: usize) -> usize;
     pub fn rt_write_ppm(path: *const c_char, pixels_0rgb: *const u32, width: u32, height: u32) -> c_int;
+    pub fn rt_obj_count(path: *const c_char, n_tris: *mut usize, n_models: *mut usize, n_faces: *mut usize) -> c_int;
 }
 
 /// What `render(width, height, &event_loop, &mut pool)` (main.rs:444) becomes: the block callback

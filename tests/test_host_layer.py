@@ -445,3 +445,35 @@ def test_headless_main_fails_loudly_without_a_gpu(rt):
     out = subprocess.run([exe, "--scene", "cornell_plane", "--obj", asset("cornell_box_plane.obj"), "--size", "32x32",
                           "--spp", "2", "--out", os.devnull], capture_output=True, text=True, timeout=60)
     assert out.returncode == 1 and "rt_context_create" in out.stderr
+
+
+def test_rust_bindings_cover_the_headers():
+    """rust/raytracer-gpu-sys/src/lib.rs cannot be compiled here (no Rust toolchain), so its text is
+    held against the headers: every C function is declared once with the same number of
+    arguments, and every enumerator / flag it names has the header's value."""
+    def strip(text):
+        return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    c_funcs, c_consts = {}, {}
+    for header in ("rt_abi.h", "rt_host.h"):
+        text = strip(open(os.path.join(ROOT, "include", header)).read())
+        for m in re.finditer(r"^[\w \*]+?\b(rt_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.M):
+            args = m.group(2).strip()
+            c_funcs[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+        for body in re.findall(r"enum\s*\{(.*?)\}", text, flags=re.S):
+            for name, val in re.findall(r"(RT_\w+)\s*=\s*(-?\w+)", body):
+                c_consts[name] = int(val, 0)
+        for name, val in re.findall(r"#define\s+(RT_\w+)\s+(0x[0-9A-Fa-f]+|\d+)u?\b", text):
+            c_consts[name] = int(val, 0)
+    rust = open(os.path.join(ROOT, "rust", "raytracer-gpu-sys", "src", "lib.rs")).read()
+    rust = re.sub(r"//[^\n]*", "", rust)
+    r_funcs = {}
+    for m in re.finditer(r"pub fn (rt_\w+)\s*\((.*?)\)\s*(?:->[^;]*)?;", rust, flags=re.S):
+        assert m.group(1) not in r_funcs, m.group(1)
+        args = m.group(2).strip()
+        r_funcs[m.group(1)] = 0 if not args else len(re.findall(r"\w+\s*:", args))
+    assert r_funcs == c_funcs
+    r_consts = {n: int(v.replace("_", ""), 0) for n, v in re.findall(r"pub const (RT_\w+): \w+ = (-?[0-9A-Fa-fx_]+);", rust)}
+    assert len(r_consts) >= 20
+    for name, val in r_consts.items():
+        assert name in c_consts, name
+        assert c_consts[name] == val or (name == "RT_MISS" and val == 0xFFFFFFFF), name
