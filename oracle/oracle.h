@@ -12,7 +12,10 @@
  * crates glam 0.8.7 (Vec3 arithmetic: dot association, normalize, min/max) and tobj 3.2.2
  * (OBJ triangulation) is "parity unpinned".  What IS pinned: the xorshift32 stream, the
  * random01 bit patterns, the create_world1 sphere table and the OBJ triangle counts, all
- * derived from the reference's definitions and checked in tests/test_oracle_kat.py.
+ * derived from the reference's definitions and checked in tests/test_oracle_kat.py; and, at
+ * image level, the whole pipeline (OBJ ingest, camera, trees, materials, tonemap) by the one
+ * rendered frame the reference ships, screenshot.png of its default job, which this oracle
+ * reproduces block for block within Monte-Carlo noise (same test file).
  *
  * The C API below is what tests bind with ctypes.
  */

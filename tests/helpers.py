@@ -132,3 +132,72 @@ def assert_hits_equal(got, want, t_rtol=0.0):
     fin = hit & np.isfinite(want["p"]).all(axis=-1) & np.isfinite(want["n"]).all(axis=-1)
     np.testing.assert_allclose(got["p"][fin], want["p"][fin], rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(got["n"][fin], want["n"][fin], rtol=1e-6, atol=1e-6)
+
+
+def read_png(path):
+    """8-bit RGB / RGBA, non-interlaced PNG -> uint8 array [h, w, channels] (standard library only)."""
+    import struct
+    import zlib
+    d = open(path, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(d):
+        n, = struct.unpack(">I", d[pos:pos + 4])
+        tag, body = d[pos + 4:pos + 8], d[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ctype, _, _, interlace = hdr
+    assert depth == 8 and ctype in (2, 6) and interlace == 0
+    bpp = 3 if ctype == 2 else 4
+    raw = zlib.decompress(idat)
+    stride = w * bpp
+    out = np.zeros((h, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    for y in range(h):
+        f = raw[y * (stride + 1)]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=y * (stride + 1) + 1).astype(np.int32)
+        if f == 0:
+            cur = line
+        elif f == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if f == 1:
+                    p = a
+                elif f == 3:
+                    p = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + p) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w, bpp)
+
+
+def reference_screenshot():
+    """The one rendered frame the reference ships (screenshot.png, copied to tests/golden/ as data):
+    a grab of its window after the default job has finished -- cornell_box.obj, 400 x 400,
+    400 samples per pixel, 6 bounces (main.rs:20-24, 322).  Returns the window's client area
+    (below the 38-pixel title bar, inside the 1-pixel border) as float RGB in [0, 1], [400, 400, 3]."""
+    im = read_png(os.path.join(ROOT, "tests", "golden", "reference_screenshot.png"))
+    assert im.shape == (439, 402, 4)
+    return im[38:438, 1:401, :3].astype(np.float64) / 255.0
+
+
+def unpack_0rgb(packed, h, w):
+    """0x00RRGGBB pixels -> float RGB in [0, 1], [h, w, 3]"""
+    p = np.asarray(packed, dtype=np.uint32).reshape(h, w)
+    return np.stack([(p >> 16) & 255, (p >> 8) & 255, p & 255], axis=-1).astype(np.float64) / 255.0
+
+
+def block_means(a, k):
+    h, w, c = a.shape
+    return a.reshape(h // k, k, w // k, k, c).mean(axis=(1, 3))

@@ -336,3 +336,30 @@ def test_headless_main_writes_the_library_frame(rt, ob, ctx, tmp_path):
     prog, text = run("--progressive")
     assert "block events" in text
     assert np.abs(prog.astype(int) - want_rgb.astype(int)).max() <= 1
+
+
+def test_frame_against_the_reference_screenshot(rt, ob, ctx):
+    """The reference ships one rendered frame: screenshot.png, its window after the default job has
+    finished (cornell_box.obj, 400 x 400, 400 samples per pixel, 6 bounces: main.rs:20-24, 322).  The
+    same job on the GPU, tonemapped and packed as the reference does (main.rs:369-373), must be that
+    picture up to Monte-Carlo noise at matched spp:
+      per-pixel RMSE(gpu, screenshot) <= 1.10 x RMSE(gpu, gpu with another seed)   (stated bound),
+      means of 20 x 20-pixel blocks within 0.005 RMS and 0.02 at worst, image means within 0.002
+    (values in [0, 1]; measured: 0.0456 vs a floor of 0.0456, 0.0023, 0.0099, 0.0002)."""
+    from helpers import block_means, reference_screenshot, unpack_0rgb
+    shot = reference_screenshot()
+    world = rt.World.cornell_box(ctx, asset("cornell_box.obj"))
+    cam = world.camera(400, 400)
+    frames = []
+    for seed in (rt.DEFAULT_SEED, 2024):
+        acc, st = world.scene.render(cam, world.params(400, 400, 400, 6, seed=seed))
+        frames.append(unpack_0rgb(ctx.tonemap(acc, 400), 400, 400))
+    world.close()
+    rmse = lambda a, b: float(np.sqrt(((a - b) ** 2).mean()))
+    floor = rmse(frames[0], frames[1])
+    err = max(rmse(frames[0], shot), rmse(frames[1], shot))
+    d = block_means(shot, 20) - block_means(frames[0], 20)
+    print(f"gpu vs the reference's screenshot at 400 spp: per-pixel rmse {err:.4f} (gpu vs gpu {floor:.4f}), "
+          f"block rmse {np.sqrt((d ** 2).mean()):.4f}, worst block {np.abs(d).max():.4f}, mean difference {d.mean():+.5f}")
+    assert err <= 1.10 * floor
+    assert np.sqrt((d ** 2).mean()) < 0.005 and np.abs(d).max() < 0.02 and abs(d.mean()) < 0.002

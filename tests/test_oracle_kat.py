@@ -237,3 +237,22 @@ def test_render_is_deterministic_and_counts(ob):
     d1, _, st1 = s.render(64, 64, 2, 1)
     assert st1["rays"] == st1["paths"] and d1.max() == 20.0
     assert ((d1 <= 1.0) | (d1 >= 10.0)).all()
+
+
+def test_oracle_frame_against_the_reference_screenshot(ob):
+    """The only output of the reference that exists: screenshot.png, its window after the default
+    job (cornell_box.obj, 400 x 400, 400 spp, 6 bounces) has finished.  The oracle renders that job
+    at 64 spp (400 would take minutes on these cores) and must show the same picture: means of
+    20 x 20-pixel blocks within 0.015 RMS and 0.04 at worst, of a [0, 1] range.  (The displayed value
+    is sqrt(mean radiance): at fewer samples its expectation is slightly lower, 0.006 on average
+    here, which is inside the bound.  The GPU tests make the comparison at the full 400 spp.)"""
+    from helpers import asset, block_means, reference_screenshot, unpack_0rgb
+    shot = reference_screenshot()
+    osc = ob.Scene.cornell_box(asset("cornell_box.obj"))
+    _, img, st = osc.render(400, 400, 64, 6, nthreads=8)
+    mine = unpack_0rgb(img, 400, 400)
+    d = block_means(shot, 20) - block_means(mine, 20)
+    print(f"oracle at 64 spp vs the reference's screenshot: block rmse {np.sqrt((d ** 2).mean()):.4f}, "
+          f"worst block {np.abs(d).max():.4f}, mean difference {d.mean():+.4f}")
+    assert np.sqrt((d ** 2).mean()) < 0.015 and np.abs(d).max() < 0.04
+    assert abs(d.mean()) < 0.012
