@@ -196,7 +196,7 @@ struct ObjData {
     std::vector<std::string> material_names;   // newmtl order of the MTL file
     size_t n_faces = 0;
 };
-// returns an empty string on success
-std::string load_obj(const std::string& path, ObjData& out);
+// returns an empty string on success; threads = 0: one chunk per 4 MB of text, up to the cores (or RT_OBJ_THREADS)
+std::string load_obj(const std::string& path, ObjData& out, int threads = 0);
 
 }  // namespace rthost

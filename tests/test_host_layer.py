@@ -133,6 +133,53 @@ f 3//1 4//1 5//1
     assert rt.obj_count(path) == want == (8, 3, 5)      # quad 2 + tri 1 | tri 1 + pentagon 3 | tri 1
 
 
+def test_obj_loader_chunks_give_the_single_pass_result(rt, ob, tmp_path, monkeypatch):
+    """The loader parses a file in chunks cut at line ends (one per thread on big files) and replays
+    the state-changing lines in file order.  Whatever the number of chunks -- forced here through
+    RT_OBJ_THREADS on files of a few lines to a few MB, so that cuts fall between every kind of
+    line -- models, faces and triangles must be those of one chunk: relative indices, material
+    changes and object names straddling the cuts included."""
+    lines = ["mtllib m.mtl"]
+    rng = np.random.default_rng(5)
+    n_v = 0
+    for obj in range(7):
+        lines.append(f"o part{obj}")
+        for f in range(9):
+            if f % 3 == 0:
+                lines.append("usemtl " + ["white", "red", "green", "nosuch"][(obj + f) % 4])
+            pts = rng.uniform(-1, 1, (4, 3))
+            for q in pts:
+                lines.append("v %.6f %.6f %.6f" % tuple(q))
+            lines.append("vn %.6f %.6f %.6f" % tuple(rng.uniform(-1, 1, 3)))
+            n_v += 4
+            if f % 2:
+                lines.append(f"f -4//-1 -3//-1 -2//-1 -1//-1")
+            else:
+                lines.append(f"f {n_v - 3}//{obj * 9 + f + 1} {n_v - 2}//{obj * 9 + f + 1} {n_v}//{obj * 9 + f + 1}")
+    (tmp_path / "m.mtl").write_text("newmtl white\nnewmtl red\nnewmtl green\n")
+    (tmp_path / "gen.obj").write_text("\n".join(lines))            # no newline at the end
+    files = [str(tmp_path / "gen.obj"), asset("cornell_box.obj"), asset("cornell_box_plane.obj"), asset("thing.obj")]
+    for path in files:
+        monkeypatch.setenv("RT_OBJ_THREADS", "1")
+        want_count = rt.obj_count(path)
+        assert want_count == ob.obj_count(path)
+        w = rt.World.cornell_box(None, path)
+        want = w.objects()
+        w.close()
+        for n in (2, 3, 5, 16, 61):
+            monkeypatch.setenv("RT_OBJ_THREADS", str(n))
+            assert rt.obj_count(path) == want_count
+            w = rt.World.cornell_box(None, path)
+            got = w.objects()
+            w.close()
+            assert len(got) == len(want)
+            for (ka, a), (kb, b) in zip(got, want):
+                assert ka == kb and np.array_equal(a, b)
+    monkeypatch.delenv("RT_OBJ_THREADS")
+    n_tris, _, n_faces = rt.obj_count(files[0])
+    assert n_faces == 63 and n_tris == 63 + 7 * 4      # 28 of the faces are quads
+
+
 def test_camera_setup_matches_oracle(rt, ob):
     rng = np.random.default_rng(0)
     for _ in range(20):
