@@ -524,3 +524,34 @@ def test_rust_bindings_cover_the_headers():
     for name, val in r_consts.items():
         assert name in c_consts, name
         assert c_consts[name] == val or (name == "RT_MISS" and val == 0xFFFFFFFF), name
+
+
+def test_headers_are_plain_c_and_link_from_c(tmp_path):
+    """The boundary is a C ABI: both headers must compile as strict C99 (no C++ in them), and a C
+    program must link against the library with nothing but the headers."""
+    import subprocess
+    src = tmp_path / "c_check.c"
+    src.write_text('''#include "rt_abi.h"
+#include "rt_host.h"
+#include <stdio.h>
+int main(void) {
+    rt_context* ctx = 0;
+    rt_material m; rt_sphere s; rt_triangle t; rt_ray r; rt_hit h; rt_camera c; rt_render_params p; rt_stats st;
+    (void)m; (void)s; (void)t; (void)r; (void)h; (void)c; (void)p; (void)st;
+    printf("%d %d %d %d %d %d %d %d\\n", (int)sizeof m, (int)sizeof s, (int)sizeof t, (int)sizeof r, (int)sizeof h,
+           (int)sizeof c, (int)sizeof p, (int)sizeof st);
+    if (rt_context_create(-1, &ctx) == RT_OK) return 1;      /* must fail: no such device */
+    printf("%s\\n", rt_last_error());
+    return 0;
+}
+''')
+    inc = os.path.join(ROOT, "include")
+    lib = os.path.join(ROOT, "raytracer_amd")
+    exe = tmp_path / "c_check"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{inc}", str(src), "-o", str(exe),
+                    f"-L{lib}", "-l:librt_amd.so", f"-Wl,-rpath,{lib}"], check=True, capture_output=True, text=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    sizes = [int(v) for v in out.stdout.splitlines()[0].split()]
+    assert sizes == [24, 20, 52, 24, 40, 76, 80, 72]           # the layouts the Python and Rust stubs assume
+    assert out.stdout.splitlines()[1].strip()                  # a message, not an empty string
