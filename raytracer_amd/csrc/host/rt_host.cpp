@@ -27,6 +27,15 @@ int host_fail(const std::string& msg) {
     return RT_ERR_INVALID;
 }
 
+// no exception may cross the C ABI
+#define RT_HOST_GUARD_BEGIN try {
+#define RT_HOST_GUARD_END(name)                                                        \
+    } catch (const std::exception& e) {                                                \
+        return host_fail(std::string(name ": ") + e.what());                           \
+    } catch (...) {                                                                    \
+        return host_fail(name ": unknown exception");                                  \
+    }
+
 template <class F>
 int make_world(rt_context* ctx, rt_world** out, F&& ctor) {
     if (!out) return host_fail("rt_world_create: out is NULL");
@@ -38,6 +47,8 @@ int make_world(rt_context* ctx, rt_world** out, F&& ctor) {
         return RT_OK;
     } catch (const std::exception& e) {
         return host_fail(e.what());
+    } catch (...) {
+        return host_fail("rt_world_create: unknown exception");
     }
 }
 
@@ -67,19 +78,23 @@ rt_scene* rt_world_scene(rt_world* w) { return w ? w->renderer->scene() : nullpt
 float rt_world_sky_intensity(const rt_world* w) { return w ? w->renderer->world().sky_intensity : 0.0f; }
 
 int rt_world_camera(const rt_world* w, float aspect_ratio, rt_camera* out) {
+    RT_HOST_GUARD_BEGIN
     if (!w || !out) return host_fail("rt_world_camera: NULL argument");
     Camera c = w->renderer->world().camera;
     c.setup(aspect_ratio);
     *out = c.describe();
     return RT_OK;
+    RT_HOST_GUARD_END("rt_world_camera")
 }
 
 size_t rt_world_num_materials(const rt_world* w) { return w ? w->renderer->description().materials.size() : 0; }
 int rt_world_get_materials(const rt_world* w, rt_material* out) {
+    RT_HOST_GUARD_BEGIN
     if (!w || !out) return host_fail("rt_world_get_materials: NULL argument");
     const auto& m = w->renderer->description().materials;
     std::memcpy(out, m.data(), m.size() * sizeof(rt_material));
     return RT_OK;
+    RT_HOST_GUARD_END("rt_world_get_materials")
 }
 size_t rt_world_num_objects(const rt_world* w) { return w ? w->renderer->description().objects.size() : 0; }
 int rt_world_object_info(const rt_world* w, size_t i, size_t* count) {
@@ -94,27 +109,33 @@ int rt_world_get_sphere(const rt_world* w, size_t i, rt_sphere* out) {
     return RT_OK;
 }
 int rt_world_get_mesh(const rt_world* w, size_t i, rt_triangle* out) {
+    RT_HOST_GUARD_BEGIN
     if (!w || !out || i >= w->renderer->description().objects.size()) return host_fail("rt_world_get_mesh: bad argument");
     const auto& t = w->renderer->description().objects[i].tris;
     std::memcpy(out, t.data(), t.size() * sizeof(rt_triangle));
     return RT_OK;
+    RT_HOST_GUARD_END("rt_world_get_mesh")
 }
 int rt_world_root_kind(const rt_world* w) { return w ? w->renderer->description().root_kind : -1; }
 
 int rt_camera_setup(const float f[3], const float a[3], const float u[3], float vfov, float aperture,
                     float focus_dist, float aspect_ratio, rt_camera* out) {
+    RT_HOST_GUARD_BEGIN
     if (!f || !a || !u || !out) return host_fail("rt_camera_setup: NULL argument");
     Camera c(Vec3(f[0], f[1], f[2]), Vec3(a[0], a[1], a[2]), Vec3(u[0], u[1], u[2]), vfov, aperture, focus_dist);
     c.setup(aspect_ratio);
     *out = c.describe();
     return RT_OK;
+    RT_HOST_GUARD_END("rt_camera_setup")
 }
 
 int rt_world_render(rt_world* w, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
                     uint64_t seed, float* accum_rgb, rt_stats* stats) {
+    RT_HOST_GUARD_BEGIN
     if (!w || !accum_rgb) return host_fail("rt_world_render: NULL argument");
     if (spp == 0) return host_fail("rt_world_render: spp must be positive");
     return w->renderer->render(width, height, spp, max_bounces, seed, accum_rgb, stats);
+    RT_HOST_GUARD_END("rt_world_render")
 }
 
 size_t rt_progressive_schedule(uint32_t spp, uint32_t* counts, size_t cap) {
@@ -125,13 +146,16 @@ size_t rt_progressive_schedule(uint32_t spp, uint32_t* counts, size_t cap) {
 
 int rt_world_render_progressive(rt_world* w, uint32_t width, uint32_t height, uint32_t spp, uint32_t max_bounces,
                                 uint64_t seed, rt_block_fn on_block, void* user, float* accum_rgb, rt_stats* stats) {
+    RT_HOST_GUARD_BEGIN
     if (!w) return host_fail("rt_world_render_progressive: NULL world");
     if (spp == 0) return host_fail("rt_world_render_progressive: spp must be positive");
     if (width < 2 || height < 2) return host_fail("rt_world_render_progressive: width and height must be at least 2");
     return w->renderer->render_progressive(width, height, spp, max_bounces, seed, on_block, user, accum_rgb, stats);
+    RT_HOST_GUARD_END("rt_world_render_progressive")
 }
 
 int rt_write_ppm(const char* path, const uint32_t* px, uint32_t width, uint32_t height) {
+    RT_HOST_GUARD_BEGIN
     if (!path || !px) return host_fail("rt_write_ppm: NULL argument");
     FILE* f = std::fopen(path, "wb");
     if (!f) return host_fail(std::string("rt_write_ppm: cannot open ") + path);
@@ -147,9 +171,11 @@ int rt_write_ppm(const char* path, const uint32_t* px, uint32_t width, uint32_t 
     }
     ok = std::fclose(f) == 0 && ok;
     return ok ? RT_OK : host_fail(std::string("rt_write_ppm: write failed: ") + path);
+    RT_HOST_GUARD_END("rt_write_ppm")
 }
 
 int rt_obj_count(const char* path, size_t* n_tris, size_t* n_models, size_t* n_faces) {
+    RT_HOST_GUARD_BEGIN
     if (!path) return host_fail("rt_obj_count: NULL path");
     ObjData d;
     const std::string err = load_obj(path, d);
@@ -160,6 +186,7 @@ int rt_obj_count(const char* path, size_t* n_tris, size_t* n_models, size_t* n_f
     if (n_models) *n_models = d.models.size();
     if (n_faces) *n_faces = d.n_faces;
     return RT_OK;
+    RT_HOST_GUARD_END("rt_obj_count")
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,18 @@ namespace {
         if (e_ != hipSuccess)                                                                      \
             return fail(RT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
+
+// No exception may cross the C ABI: the entry points that allocate on the host (or start threads)
+// run inside these brackets and turn what is thrown into a status and a message.
+#define RT_GUARD_BEGIN try {
+#define RT_GUARD_END(name)                                                                         \
+    } catch (const std::bad_alloc&) {                                                              \
+        return fail(RT_ERR_NOMEM, name ": out of host memory");                                    \
+    } catch (const std::exception& e) {                                                            \
+        return fail(RT_ERR_INVALID, std::string(name ": ") + e.what());                            \
+    } catch (...) {                                                                                \
+        return fail(RT_ERR_INVALID, name ": unknown exception");                                   \
+    }
 
 struct DeviceBuffer {
     void* p = nullptr;
@@ -177,6 +190,7 @@ extern "C" {
 const char* rt_last_error(void) { return g_last_error.c_str(); }
 
 int rt_context_create(int device_id, rt_context** out) {
+    RT_GUARD_BEGIN
     if (!out) return fail(RT_ERR_INVALID, "rt_context_create: out is NULL");
     *out = nullptr;
     int n = 0;
@@ -213,6 +227,7 @@ int rt_context_create(int device_id, rt_context** out) {
     if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::min(MAX_PIPES, std::max(1, std::atoi(e)));
     *out = ctx.release();
     return RT_OK;
+    RT_GUARD_END("rt_context_create")
 }
 
 void rt_context_destroy(rt_context* ctx) {
@@ -235,6 +250,7 @@ int rt_context_synchronize(rt_context* ctx) {
 }
 
 int rt_scene_create(rt_context* ctx, rt_scene** out) {
+    RT_GUARD_BEGIN
     // ctx may be NULL: the scene is then host-only (it can be committed and its flattened
     // entries inspected, but nothing can be traced or rendered with it)
     if (!out) return fail(RT_ERR_INVALID, "rt_scene_create: NULL argument");
@@ -244,6 +260,7 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
     (*out)->build_mode = g_default_build.load();
     if (ctx) ctx->refs.fetch_add(1);
     return RT_OK;
+    RT_GUARD_END("rt_scene_create")
 }
 
 void rt_scene_destroy(rt_scene* scene) {
@@ -259,13 +276,16 @@ void rt_scene_destroy(rt_scene* scene) {
 }
 
 int rt_scene_set_materials(rt_scene* s, const rt_material* mats, size_t n) {
+    RT_GUARD_BEGIN
     if (!s || (!mats && n)) return fail(RT_ERR_INVALID, "rt_scene_set_materials: NULL argument");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     s->mats.assign(mats, mats + n);
     return RT_OK;
+    RT_GUARD_END("rt_scene_set_materials")
 }
 
 int rt_scene_add_spheres(rt_scene* s, const rt_sphere* sp, size_t n) {
+    RT_GUARD_BEGIN
     if (!s || (!sp && n)) return fail(RT_ERR_INVALID, "rt_scene_add_spheres: NULL argument");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     for (size_t i = 0; i < n; i++) {
@@ -275,9 +295,11 @@ int rt_scene_add_spheres(rt_scene* s, const rt_sphere* sp, size_t n) {
         s->objects.push_back(std::move(o));
     }
     return RT_OK;
+    RT_GUARD_END("rt_scene_add_spheres")
 }
 
 int rt_scene_add_mesh(rt_scene* s, const rt_triangle* tris, size_t n, const float* xform) {
+    RT_GUARD_BEGIN
     if (!s || (!tris && n)) return fail(RT_ERR_INVALID, "rt_scene_add_mesh: NULL argument");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     if (xform) {
@@ -290,6 +312,7 @@ int rt_scene_add_mesh(rt_scene* s, const rt_triangle* tris, size_t n, const floa
     o.tris.assign(tris, tris + n);
     s->objects.push_back(std::move(o));
     return RT_OK;
+    RT_GUARD_END("rt_scene_add_mesh")
 }
 
 int rt_scene_set_root(rt_scene* s, int root_kind) {
@@ -346,6 +369,7 @@ int rt_scene_set_build(rt_scene* s, int build_mode) {
 }
 
 int rt_scene_set_traversal(rt_scene* s, int mode) {
+    RT_GUARD_BEGIN
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
     if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_OCTANT) return fail(RT_ERR_INVALID, "unknown traversal mode");
     if (s->committed) {
@@ -354,9 +378,11 @@ int rt_scene_set_traversal(rt_scene* s, int mode) {
     }
     s->traversal = mode;
     return RT_OK;
+    RT_GUARD_END("rt_scene_set_traversal")
 }
 
 int rt_scene_commit(rt_scene* s) {
+    RT_GUARD_BEGIN
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->build_mode, s->flat);
@@ -426,6 +452,7 @@ int rt_scene_commit(rt_scene* s) {
     s->flat.prim_geo.clear(); s->flat.prim_geo.shrink_to_fit();
     s->committed = true;
     return RT_OK;
+    RT_GUARD_END("rt_scene_commit")
 }
 
 size_t rt_scene_num_prims(const rt_scene* s) { return s ? s->dev.n_prims : 0; }
@@ -451,6 +478,7 @@ int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
 
 int rt_trace_device(rt_scene* s, const void* d_rays, size_t n, float t_min, float t_max, void* d_hits,
                     uint64_t* counts) {
+    RT_GUARD_BEGIN
     if (!s || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "rt_trace_device: NULL argument");
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
     if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
@@ -473,9 +501,11 @@ int rt_trace_device(rt_scene* s, const void* d_rays, size_t n, float t_min, floa
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return RT_OK;
+    RT_GUARD_END("rt_trace_device")
 }
 
 int rt_trace(rt_scene* s, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out) {
+    RT_GUARD_BEGIN
     if (!s || (n && (!rays || !out))) return fail(RT_ERR_INVALID, "rt_trace: NULL argument");
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
     if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
@@ -490,10 +520,12 @@ int rt_trace(rt_scene* s, const rt_ray* rays, size_t n, float t_min, float t_max
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ctx->scratch_out.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
     return RT_OK;
+    RT_GUARD_END("rt_trace")
 }
 
 int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* p, void* d_accum,
                      rt_stats* stats) {
+    RT_GUARD_BEGIN
     if (!s || !cam || !p || !d_accum) return fail(RT_ERR_INVALID, "rt_render_device: NULL argument");
     if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
     if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
@@ -833,9 +865,11 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     { static bool dumped = false; if (!dumped && !count) { dumped = true; rtamd::dump_stamps(); } }
 #endif
     return RT_OK;
+    RT_GUARD_END("rt_render_device")
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, const rt_render_params* p, float* accum_rgb, rt_stats* stats) {
+    RT_GUARD_BEGIN
     if (!s || !p || !accum_rgb) return fail(RT_ERR_INVALID, "rt_render: NULL argument");
     if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
     rt_context* ctx = s->ctx;
@@ -850,9 +884,11 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_render_params* p, floa
     if (rc) return rc;
     HIP_TRY(hipMemcpy(accum_rgb, d.p, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
+    RT_GUARD_END("rt_render")
 }
 
 int rt_tonemap_device(rt_context* ctx, const void* d_accum, uint32_t spp, void* d_out, size_t npix) {
+    RT_GUARD_BEGIN
     if (!ctx || (npix && (!d_accum || !d_out))) return fail(RT_ERR_INVALID, "rt_tonemap_device: NULL argument");
     if (spp == 0) return fail(RT_ERR_INVALID, "spp must be positive");
     int rc = set_device(ctx);
@@ -860,9 +896,11 @@ int rt_tonemap_device(rt_context* ctx, const void* d_accum, uint32_t spp, void* 
     if (launch_tonemap(ctx->cfg(), d_accum, spp, d_out, npix)) return fail(RT_ERR_DEVICE, "tonemap launch failed");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
+    RT_GUARD_END("rt_tonemap_device")
 }
 
 int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out, size_t npix) {
+    RT_GUARD_BEGIN
     if (!ctx || (npix && (!accum_rgb || !out))) return fail(RT_ERR_INVALID, "rt_tonemap: NULL argument");
     if (npix == 0) return RT_OK;
     int rc = set_device(ctx);
@@ -875,6 +913,7 @@ int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* 
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, o.p, npix * 4, hipMemcpyDeviceToHost));
     return RT_OK;
+    RT_GUARD_END("rt_tonemap")
 }
 
 }  // extern "C"
