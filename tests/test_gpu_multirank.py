@@ -49,3 +49,29 @@ def test_one_rank_through_rccl():
     assert rccl["n_gpus"] == 1
     assert rccl["config"]["rays_per_step"] == one["config"]["rays_per_step"]
     assert rccl["config"]["accum_sum"] == one["config"]["accum_sum"]
+
+
+def test_render_module_two_ranks_write_the_one_rank_frame(tmp_path):
+    """python -m raytracer_amd.render: one rank, and two ranks (gloo, sharing the box's GPU) that split
+    the frame by row bands and sample range and reduce to rank 0.  The PPMs must agree up to the
+    last bit of 8-bit rounding (the two halves of a pixel's samples are summed separately)."""
+    import numpy as np
+    env = dict(os.environ, RT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+    args = ["--scene", "world2_glass", "--size", "96x80", "--spp", "24"]
+    frames = []
+    for n in (1, 2):
+        out = tmp_path / f"f{n}.ppm"
+        if n == 1:
+            cmd = [sys.executable, "-m", "raytracer_amd.render"]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+                   "--master-addr", "127.0.0.1", "--master-port", "29655", "-m", "raytracer_amd.render"]
+        p = subprocess.run(cmd + args + ["--out", str(out)], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        assert "Finished in" in p.stdout
+        raw = out.read_bytes()
+        header = b"P6\n96 80\n255\n"
+        assert raw.startswith(header)
+        frames.append(np.frombuffer(raw[len(header):], dtype=np.uint8).astype(int))
+    assert len(frames[0]) == 96 * 80 * 3 and frames[0].max() > 100
+    assert np.abs(frames[0] - frames[1]).max() <= 1
