@@ -160,23 +160,26 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
-    bool live = valid && n_ent_ > 0;
     uint32_t n_ent = n_ent_;                   // OCT: the end of the lane's copy
     if (OCT) { r.i = n_ent_ * octant_of(dx, dy, dz); n_ent = r.i + n_ent_; }
-    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
-    if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+    // A lane without a (further) entry holds TAG_END in the tag word of `a`: whether a lane stands at
+    // a box or at a primitive is then one compare of that word, whose lane mask is the ballot.
+    const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
+    float4 a = ended, b = ended;
+    if (valid && n_ent_ > 0) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
     for (;;) {
         const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
-        const bool at_box = live && tag == TAG_BOX;
-        const bool at_prim = live && tag != TAG_BOX;
+        const bool at_box = tag == TAG_BOX;
+        const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
+        static_assert(TAG_TRI == 1 && TAG_SPH == 2 && TAG_END == 3, "tag order");
         const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
         if ((mb | mp) == 0ull) break;
         RT_UTIL_TRIP(cnt);
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            live = r.i < n_ent;
-            if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            else a.w = ended.w;
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
@@ -190,8 +193,8 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                     sphere_step(a, b, r, t_min);
                     r.i = r.i + 1;
                 }
-                live = r.i < n_ent;
-                if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                else a.w = ended.w;
             }
         }
     }
@@ -764,10 +767,13 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
     uint32_t n_ent = n_ent_;                   // OCT: the end of the copy the lane's ray walks
-    bool has_ray = false, live = false;
+    bool has_ray = false;
     uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
-    float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a;
+    // (a lane without an entry to visit holds TAG_END in the tag word of `a`, as in closest_hit)
+    const float end_word = u2f(TAG_END << TAG_SHIFT);
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, end_word), b = a;
     for (;;) {
+        const bool live = (f2u(a.w) >> TAG_SHIFT) != TAG_END;
         const unsigned long long m_live = __ballot(live);
         const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
@@ -794,24 +800,23 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
                     slot = f2u(ra.w);
                     has_ray = true;
-                    live = n_ent_ > 0;
                     if (OCT) { r.i = n_ent_ * octant_of(rb.x, rb.y, rb.z); n_ent = r.i + n_ent_; }
-                    if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                    if (n_ent_ > 0) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
                 }
                 next = min(n, next + n_idle);
                 continue;
             }
         }
         const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
-        const bool at_box = live && tag == TAG_BOX;
-        const bool at_prim = live && tag != TAG_BOX;
+        const bool at_box = tag == TAG_BOX;
+        const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
         const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
         RT_UTIL_TRIP(cnt);
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            live = r.i < n_ent;
-            if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            else a.w = end_word;
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
@@ -825,8 +830,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     sphere_step(a, b, r, t_min);
                     r.i = r.i + 1;
                 }
-                live = r.i < n_ent;
-                if (live) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                else a.w = end_word;
             }
         }
     }
