@@ -252,6 +252,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
+                       "build": args.build, "traversal": args.traversal,
                        "partition": f"rank 0: {bands[0]}-row bands b with b % {bands[1]} == {bands[2]}, "
                                     f"samples [{samples[0]},{samples[1]})",
                        "rays_per_step": int(total_rays / args.steps), "paths_per_step": width * height * spp,

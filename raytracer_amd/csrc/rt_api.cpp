@@ -348,7 +348,7 @@ static int apply_traversal(rt_scene* s, int mode) {
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
     s->auto_tuned = false;
     s->dev.refill = s->env_refill;
-    s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : (s->dev.lds_walk && !s->dev.octant ? 4u : 8u);
+    s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
     return RT_OK;
@@ -434,10 +434,10 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 32u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
-        // on the sphere and OBJ scenes, 8 when entries come from memory, 4 when they come from LDS
+        // on the sphere and OBJ scenes, from memory and out of LDS alike (2 .. 12 lie within 3 %)
         const char* e = getenv("RT_PRIM_WAIT");
         s->env_prim_wait = e ? (uint32_t)std::max(1, atoi(e)) : 0u;
-        s->dev.prim_wait = e ? s->env_prim_wait : (s->dev.lds_walk ? 4u : 8u);
+        s->dev.prim_wait = e ? s->env_prim_wait : 8u;
     }
     {
         const char* e = getenv("RT_REFILL");
