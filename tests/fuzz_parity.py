@@ -1,5 +1,5 @@
 """Ad-hoc parity campaign: random scenes x random and adversarial rays, every traversal form against
-the oracle (primitive id exact, t bit-exact; the opt-in near-first walks: t and hit / miss).  Run on a GPU box: python tools/fuzz_parity.py [seeds]"""
+the oracle (primitive id exact, t bit-exact; the opt-in near-first walks: t and hit / miss).  Run on a GPU box: python tests/fuzz_parity.py [seeds]  (not collected by pytest: a long-running campaign)"""
 import os
 import sys
 
@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import raytracer_amd as rt                      # noqa: E402
 from oracle import binding as ob                # noqa: E402
 from helpers import adversarial_rays, random_rays, random_scene   # noqa: E402
