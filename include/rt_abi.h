@@ -181,9 +181,10 @@ size_t rt_scene_num_prims(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
 /* host-only scenes: copies the flattened pre-order entry array (16 floats per entry) */
 int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
-/* host-only scenes: the same entries as the per-lane walks read them, in 32-byte units (8 floats):
- * a box or a sphere is the first 8 floats of its entry in one unit, a triangle takes two units
- * (floats 8-11 of its entry open the second); skip links count units */
+/* host-only scenes: the same entries as the per-lane walks read them, in 16-byte units (4 floats):
+ * a box or a sphere is the first 8 floats of its entry in two units, a triangle the first 11 in
+ * three, followed by the distance to the next entry (3, or 4 where a padding unit keeps a box or
+ * sphere 32-byte aligned); skip links count units */
 size_t rt_scene_num_units(const rt_scene* scene);
 int rt_scene_get_units(const rt_scene* scene, float* out, size_t n_floats);
 

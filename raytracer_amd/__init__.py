@@ -288,8 +288,8 @@ class Scene:
         return out
 
     def units(self):
-        """The entries as the per-lane walks read them: (n_units, 8) floats."""
-        out = np.zeros((lib.rt_scene_num_units(self.h), 8), dtype=np.float32)
+        """The entries as the per-lane walks read them: (n_units, 4) floats, 16-byte units."""
+        out = np.zeros((lib.rt_scene_num_units(self.h), 4), dtype=np.float32)
         _check(lib.rt_scene_get_units(self.h, _ptr(out), out.size))
         return out
 

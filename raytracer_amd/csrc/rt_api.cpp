@@ -336,7 +336,7 @@ static int apply_traversal(rt_scene* s, int mode) {
         if (!s->d_units_oct.p && s->dev.n_units) {   // first use: the eight copies, from the device's unit array
             int rc = set_device(s->ctx);
             if (rc) return rc;
-            std::vector<uint32_t> units((size_t)s->dev.n_units * 8), oct;
+            std::vector<uint32_t> units((size_t)s->dev.n_units * 4), oct;
             HIP_TRY(hipMemcpy(units.data(), s->d_units.p, units.size() * 4, hipMemcpyDeviceToHost));
             build_octant_units(units.data(), s->dev.n_units, oct);
             HIP_TRY(s->d_units_oct.ensure(oct.size() * 4));
@@ -431,7 +431,7 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
-    s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 32u <= LDS_WALK_MAX_BYTES &&
+    s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 16u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
         // on the sphere and OBJ scenes, from memory and out of LDS alike (2 .. 12 lie within 3 %)

@@ -349,24 +349,31 @@ void annotate_children(FlatScene& out) {
     if (depth > ORDERED_MAX_DEPTH) out.ordered_ok = false;
 }
 
-// The compact form for the per-lane walks (FlatScene::units).
+// The compact form for the per-lane walks (FlatScene::units): 16-byte units, a box or a sphere in
+// two (the first two float4 of its entry), a triangle in three (its first three float4) or four:
+// the last word of a triangle's third unit holds the distance to the entry behind it, and it is
+// four where that entry is a box or a sphere that would otherwise start at an odd unit, so that
+// every box and sphere (32 bytes) starts at a multiple of 32 bytes and never straddles a line.
 void pack_units(FlatScene& out) {
     const size_t n = out.n_entries();
     auto word = [&](size_t i, int k) { uint32_t u; std::memcpy(&u, &out.entries[i * ENTRY_FLOATS + k], 4); return u; };
+    auto tag_of = [&](size_t i) { return word(i, 3) >> TAG_SHIFT; };
     std::vector<uint32_t> unit_of(n + 1);
     uint64_t u = 0;
     for (size_t i = 0; i < n; i++) {
+        // only a triangle makes the count odd, so an odd count here means the entry before is one
+        if (tag_of(i) != TAG_TRI && (u & 1u)) u++;
         unit_of[i] = (uint32_t)u;
-        u += (word(i, 3) >> TAG_SHIFT) == TAG_TRI ? 2 : 1;
+        u += tag_of(i) == TAG_TRI ? 3 : 2;
     }
     unit_of[n] = (uint32_t)u;
     if (u > ORD_RIGHT_MASK) out.ordered_ok = false;
-    out.units.assign((size_t)u * 8, 0.0f);
+    out.units.assign((size_t)u * 4, 0.0f);
     for (size_t i = 0; i < n; i++) {
         const float* e = &out.entries[i * ENTRY_FLOATS];
-        float* d = &out.units[(size_t)unit_of[i] * 8];
-        std::memcpy(d, e, 32);
-        const uint32_t tag = word(i, 3) >> TAG_SHIFT;
+        float* d = &out.units[(size_t)unit_of[i] * 4];
+        const uint32_t tag = tag_of(i);
+        std::memcpy(d, e, tag == TAG_TRI ? 48 : 32);
         if (tag == TAG_BOX) {
             const uint32_t skip = (TAG_BOX << TAG_SHIFT) | unit_of[word(i, 3) & SKIP_MASK];
             std::memcpy(&d[3], &skip, 4);
@@ -374,7 +381,8 @@ void pack_units(FlatScene& out) {
             if (link & ORD_RIGHT_MASK) link = (link & ~ORD_RIGHT_MASK) | (unit_of[link & ORD_RIGHT_MASK] & ORD_RIGHT_MASK);
             std::memcpy(&d[7], &link, 4);
         } else if (tag == TAG_TRI) {
-            std::memcpy(d + 8, e + 8, 16);     // v0v2 into the second unit
+            const uint32_t stride = unit_of[i + 1] - unit_of[i];      // 3, or 4 with a padding unit
+            std::memcpy(&d[11], &stride, 4);
         }
     }
 }
@@ -389,44 +397,44 @@ struct OctantCopy {
     uint32_t base;             // first unit of the copy in the whole array
     uint32_t oct;
 
-    uint32_t tag(uint32_t u) const { return src[(size_t)u * 8 + 3] >> TAG_SHIFT; }
+    uint32_t tag(uint32_t u) const { return src[(size_t)u * 4 + 3] >> TAG_SHIFT; }
     uint32_t end_of(uint32_t u) const {
         const uint32_t t = tag(u);
-        return t == TAG_BOX ? (src[(size_t)u * 8 + 3] & SKIP_MASK) : u + (t == TAG_TRI ? 2u : 1u);
+        return t == TAG_BOX ? (src[(size_t)u * 4 + 3] & SKIP_MASK) : u + (t == TAG_TRI ? src[(size_t)u * 4 + 11] : 2u);
     }
     // copies the subtree at unit `u` to position `at` of the copy; returns the position behind it
     uint32_t emit(uint32_t u, uint32_t at) {
         if (tag(u) != TAG_BOX) {
             const uint32_t n = end_of(u) - u;
-            std::memcpy(dst + (size_t)at * 8, src + (size_t)u * 8, (size_t)n * 32);
+            std::memcpy(dst + (size_t)at * 4, src + (size_t)u * 4, (size_t)n * 16);
             return at + n;
         }
-        std::memcpy(dst + (size_t)at * 8, src + (size_t)u * 8, 32);
-        const uint32_t end = end_of(u), link = src[(size_t)u * 8 + 7];
-        uint32_t pos = at + 1;
+        std::memcpy(dst + (size_t)at * 4, src + (size_t)u * 4, 32);
+        const uint32_t end = end_of(u), link = src[(size_t)u * 4 + 7];
+        uint32_t pos = at + 2;
         const uint32_t second = link & ORD_RIGHT_MASK;
         if (second != 0u) {
             const uint32_t axis = (link >> ORD_AXIS_SHIFT) & 3u;
             const bool dir_positive = ((oct >> axis) & 1u) == 0u;
             const bool first_is_near = dir_positive == ((link & ORD_FIRST_LOWER) != 0u);
-            pos = emit(first_is_near ? u + 1 : second, pos);
-            pos = emit(first_is_near ? second : u + 1, pos);
+            pos = emit(first_is_near ? u + 2 : second, pos);
+            pos = emit(first_is_near ? second : u + 2, pos);
         } else {
-            for (uint32_t c = u + 1; c < end; c = end_of(c)) pos = emit(c, pos);
+            for (uint32_t c = u + 2; c < end; c = end_of(c)) pos = emit(c, pos);
         }
-        dst[(size_t)at * 8 + 3] = (TAG_BOX << TAG_SHIFT) | (base + pos);
-        dst[(size_t)at * 8 + 7] = 0u;
+        dst[(size_t)at * 4 + 3] = (TAG_BOX << TAG_SHIFT) | (base + pos);
+        dst[(size_t)at * 4 + 7] = 0u;
         return pos;
     }
 };
 }  // namespace
 
 void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out) {
-    out.assign(n_units * 8 * 8, 0u);
+    out.assign(n_units * 4 * 8, 0u);
     std::vector<std::thread> workers;
     for (uint32_t oct = 0; oct < 8; oct++)
         workers.emplace_back([=, &out]() {
-            OctantCopy c{units, out.data() + (size_t)oct * n_units * 8, (uint32_t)(oct * n_units), oct};
+            OctantCopy c{units, out.data() + (size_t)oct * n_units * 4, (uint32_t)(oct * n_units), oct};
             uint32_t pos = 0;
             for (uint32_t u = 0; u < n_units; u = c.end_of(u)) pos = c.emit(u, pos);   // top-level entries in order
         });

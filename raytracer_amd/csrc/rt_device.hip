@@ -78,7 +78,7 @@ __device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, c
     const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
     const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
     const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
-    return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : r.i + 1;
+    return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : r.i + 2;             // a box takes two units: its first child follows it
 }
 
 // shape.rs:411-450 on the triangle (a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2, b.w = prim id)
@@ -140,9 +140,11 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
 #endif
 // Per-lane walk of a whole wave (call converged; lanes without a ray pass valid = false).  Every
 // lane visits its own entries in the reference's order.  `ent` is the compact form of the entry
-// array: 32-byte units (two float4), a box or a sphere in one unit, a triangle in two (its v0v2
-// in the second); cursors and skip links count units.  A box visit therefore touches 32 bytes,
-// and a box and its first child usually share a 64-byte line.  A lane that stands at a primitive waits
+// array: 16-byte units (one float4 each), a box or a sphere in two units, a triangle in three (the
+// third holds its v0v2 and, in its last word, the distance to the next entry: 3, or 4 where a
+// padding unit keeps the box or sphere behind it 32-byte aligned); cursors and skip links count units, so a cursor is the index of the
+// entry's first float4.  A box visit therefore touches 32 bytes, and a box and its first child
+// are neighbours in memory.  A lane that stands at a primitive waits
 // there while boxes remain to be tested by other lanes, until prim_wait lanes stand at
 // primitives (or no lane stands at a box): the long primitive routines then run with many lanes
 // instead of once per loop trip for a few.
@@ -166,7 +168,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     // a box or at a primitive is then one compare of that word, whose lane mask is the ballot.
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
     float4 a = ended, b = ended;
-    if (valid && n_ent_ > 0) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+    if (valid && n_ent_ > 0) { a = ent[r.i]; b = ent[r.i + 1]; }
     for (;;) {
         const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
         const bool at_box = tag == TAG_BOX;
@@ -178,22 +180,22 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
             else a.w = ended.w;
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
-                    const float4 c = ent[2 * r.i + 2];
+                    const float4 c = ent[r.i + 2];
                     tri_step(a, b, c, r, t_min);
-                    r.i = r.i + 2;             // a triangle takes two 32-byte units
+                    r.i = r.i + f2u(c.w);      // a triangle takes three units, or four with padding behind it
                 } else {
                     if (COUNT) cnt.sph++;
                     sphere_step(a, b, r, t_min);
-                    r.i = r.i + 1;
+                    r.i = r.i + 2;
                 }
-                if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
                 else a.w = ended.w;
             }
         }
@@ -238,11 +240,11 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
         else { sp--; r.i = stack[sp * 64u + lane]; }
         live = r.i < n_ent;
         if (live) {
-            a = ent[2 * r.i];
-            b = ent[2 * r.i + 1];
+            a = ent[r.i];
+            b = ent[r.i + 1];
             if (from_top) {
                 const uint32_t tg = f2u(a.w) >> TAG_SHIFT;
-                top = tg == TAG_BOX ? (f2u(a.w) & SKIP_MASK) : r.i + (tg == TAG_TRI ? 2u : 1u);
+                top = tg == TAG_BOX ? (f2u(a.w) & SKIP_MASK) : r.i + (tg == TAG_TRI ? f2u(ent[r.i + 2].w) : 2u);
             }
         }
     };
@@ -258,7 +260,7 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
             if (box_hit(a, b, r, t_min)) {
                 const uint32_t link = f2u(b.w);
                 const uint32_t second = link & ORD_RIGHT_MASK;
-                uint32_t next = r.i + 1;
+                uint32_t next = r.i + 2;
                 if (second != 0u) {
                     const uint32_t axis = (link >> ORD_AXIS_SHIFT) & 3u;
                     const float d = axis == 0u ? dx : (axis == 1u ? dy : dz);
@@ -268,8 +270,8 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
                     next = first_is_near ? next : second;
                 }
                 r.i = next;
-                a = ent[2 * next];
-                b = ent[2 * next + 1];
+                a = ent[next];
+                b = ent[next + 1];
             } else {
                 pop();
             }
@@ -278,7 +280,7 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
             if (at_prim) {
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
-                    const float4 c = ent[2 * r.i + 2];
+                    const float4 c = ent[r.i + 2];
                     tri_step(a, b, c, r, t_min);
                 } else {
                     if (COUNT) cnt.sph++;
@@ -801,7 +803,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) { r.i = n_ent_ * octant_of(rb.x, rb.y, rb.z); n_ent = r.i + n_ent_; }
-                    if (n_ent_ > 0) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                    if (n_ent_ > 0) { a = ent[r.i]; b = ent[r.i + 1]; }
                 }
                 next = min(n, next + n_idle);
                 continue;
@@ -815,22 +817,22 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+            if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
             else a.w = end_word;
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
-                    const float4 c = ent[2 * r.i + 2];
+                    const float4 c = ent[r.i + 2];
                     tri_step(a, b, c, r, t_min);
-                    r.i = r.i + 2;
+                    r.i = r.i + f2u(c.w);
                 } else {
                     if (COUNT) cnt.sph++;
                     sphere_step(a, b, r, t_min);
-                    r.i = r.i + 1;
+                    r.i = r.i + 2;
                 }
-                if (r.i < n_ent) { a = ent[2 * r.i]; b = ent[2 * r.i + 1]; }
+                if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
                 else a.w = end_word;
             }
         }
@@ -1137,7 +1139,7 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
     if (SWEEP == 4 || SWEEP == 6) {
         const float4* src = (const float4*)sc.units;
         float4* dst = (float4*)lds_stack;
-        for (uint32_t i = threadIdx.x; i < 2u * sc.n_units; i += RT_LDS_BLOCK) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_units; i += RT_LDS_BLOCK) dst[i] = src[i];
         __syncthreads();                       // before any wave of the workgroup may leave
     }
     if (seg >= g.n_seg) return;
@@ -1305,7 +1307,7 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
     hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
     if (sc.lds_walk && !sc.ordered && !sc.sweep && !sc.octant) {
-        const size_t bytes = (size_t)sc.n_units * 32u;
+        const size_t bytes = (size_t)sc.n_units * 16u;
 #define RT_PATH_LDS(SWP)                                                                                \
         hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
                            bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \

@@ -54,11 +54,11 @@ struct FlatScene {
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
     bool has_spheres = false;
-    // The same entries packed for the per-lane walks: 8 floats per 32-byte unit; a box or a sphere
-    // is its first two float4 in one unit, a triangle takes two units (the second holds v0v2);
-    // skip links and child links count units.
+    // The same entries packed for the per-lane walks in 16-byte units (one float4 each): a box or a
+    // sphere is the first two float4 of its entry, a triangle the first three; skip links and child
+    // links count units.
     std::vector<float> units;
-    size_t n_units() const { return units.size() / 8; }
+    size_t n_units() const { return units.size() / 4; }
     uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
     bool ordered_ok = false;           // box entries carry the child links of the ordered walk
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
@@ -91,7 +91,7 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
     const void* entries;      // float4[4 * n_entries] (+ the TAG_END entry): the wave sweep's form
-    const void* units;        // float4[2 * n_units]: the per-lane walks' form
+    const void* units;        // float4[n_units]: the per-lane walks' form
     const void* prim_geo;     // float4[n_prims]
     const uint32_t* prim_meta;
     const void* materials;    // float4[2 * n_mats]
@@ -107,7 +107,7 @@ struct DevScene {
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
     uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
     uint32_t refill;          // per-lane walk in the fused kernel: idle lanes that trigger a refill from the segment (0: off)
-    const void* units_oct;    // float4[8 * 2 * n_units]: the unit array once per direction octant (octant walk)
+    const void* units_oct;    // float4[8 * n_units]: the unit array once per direction octant (octant walk)
     uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
 };
 

@@ -431,33 +431,39 @@ def test_entry_layout_small_cases(rt, ob):
 
 
 def test_units_are_the_entries_repacked(rt, ob):
-    """The per-lane walks read 32-byte units: boxes and spheres one unit, triangles two, links in
-    units.  Walking the units must give the entries back, with every link mapped."""
+    """The per-lane walks read 16-byte units: a box or a sphere is the first two float4 of its entry,
+    a triangle the first three (plus the distance to the next entry, which is 4 where a padding unit
+    follows), links count units.  Walking the units must give the entries back, with every link
+    mapped."""
     mats, objects, _ = random_scene(ob, 31, n_spheres=17, n_meshes=2, tris_per_mesh=23, extent=5.0)
     sc = rt.Scene(None, mats, objects, 0)
     ent, units = sc.entries(), sc.units()
+    assert units.shape[1] == 4
     eu, uu = ent.view(np.uint32), units.view(np.uint32)
     unit_of, u = [], 0
     for i in range(len(ent)):
+        if (eu[i, 3] >> 30) != 1 and u % 2:       # boxes and spheres start at even units (32-byte aligned):
+            u += 1                                # a padding unit behind the triangle before them
         unit_of.append(u)
-        u += 2 if (eu[i, 3] >> 30) == 1 else 1
+        u += 3 if (eu[i, 3] >> 30) == 1 else 2
     unit_of.append(u)
     assert u == len(units)
+    assert any(b - a == 4 for a, b in zip(unit_of, unit_of[1:]))
     for i in range(len(ent)):
         tag, k = int(eu[i, 3] >> 30), unit_of[i]
         assert int(uu[k, 3] >> 30) == tag
         np.testing.assert_array_equal(units[k, 0:3], ent[i, 0:3])
-        np.testing.assert_array_equal(units[k, 4:7], ent[i, 4:7])
+        np.testing.assert_array_equal(units[k + 1, 0:3], ent[i, 4:7])
         if tag == 0:
             assert int(uu[k, 3] & 0x3FFFFFFF) == unit_of[int(eu[i, 3] & 0x3FFFFFFF)]
             second = int(eu[i, 7] & 0x1FFFFFFF)
-            assert int(uu[k, 7] & 0x1FFFFFFF) == (unit_of[second] if second else 0)
-            assert int(uu[k, 7] >> 29) == int(eu[i, 7] >> 29)
+            assert int(uu[k + 1, 3] & 0x1FFFFFFF) == (unit_of[second] if second else 0)
+            assert int(uu[k + 1, 3] >> 29) == int(eu[i, 7] >> 29)
         else:
-            assert uu[k, 7] == eu[i, 7]                                   # primitive id
+            assert uu[k + 1, 3] == eu[i, 7]                               # primitive id
             if tag == 1:
-                np.testing.assert_array_equal(units[k + 1, 0:4], ent[i, 8:12])
-                assert not units[k + 1, 4:].any()
+                np.testing.assert_array_equal(units[k + 2, 0:3], ent[i, 8:11])
+                assert uu[k + 2, 3] == unit_of[i + 1] - k          # distance to the next entry: 3 or 4
 
 
 def test_progressive_schedule_and_ppm(rt, tmp_path):
