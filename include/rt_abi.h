@@ -169,7 +169,7 @@ int rt_set_default_build(int build_mode);
  * copies of the flattened trees, one per sign combination of a ray's direction, each in the
  * pre-order in which that octant's rays meet the nearer child of every box first; a ray walks the
  * copy of its octant with the same skip links as PER_LANE.  Eight times the tree memory (the
- * 10 M-triangle scene: 6.9 GB of the 288 GB) buys the ordered walk's culling at the plain walk's
+ * 10 M-triangle scene: about 6.5 GB of the 288 GB) buys the ordered walk's culling at the plain walk's
  * cost per visit.  Same caveat on ties and same limits as ORDERED; needs a device context.
  * May be called before or after rt_scene_commit(). */
 enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2, RT_TRAVERSAL_ORDERED = 3,
