@@ -330,10 +330,10 @@ static int apply_traversal(rt_scene* s, int mode) {
     if (mode == RT_TRAVERSAL_OCTANT) {
         if (!s->ordered_ok)
             return fail(RT_ERR_UNSUPPORTED, "octant traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
-        if ((uint64_t)s->dev.n_units * 8u > SKIP_MASK)
+        if (((uint64_t)s->dev.n_units + UNITS_END) * 8u > SKIP_MASK)
             return fail(RT_ERR_UNSUPPORTED, "octant traversal: eight copies of the trees exceed the 30-bit links");
         if (!s->ctx) return fail(RT_ERR_DEVICE, "octant traversal needs a device context");
-        if (!s->d_units_oct.p && s->dev.n_units) {   // first use: the eight copies, from the device's unit array
+        if (!s->d_units_oct.p) {   // first use: the eight copies, from the device's unit array
             int rc = set_device(s->ctx);
             if (rc) return rc;
             std::vector<uint32_t> units((size_t)s->dev.n_units * 4), oct;
@@ -431,7 +431,7 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_mats = (uint32_t)s->mats.size();
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
-    s->dev.lds_walk = (s->dev.n_units > 0 && (size_t)s->dev.n_units * 16u <= LDS_WALK_MAX_BYTES &&
+    s->dev.lds_walk = (s->dev.n_units > 0 && ((size_t)s->dev.n_units + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
         // on the sphere and OBJ scenes, from memory and out of LDS alike (2 .. 12 lie within 3 %)
@@ -471,8 +471,8 @@ size_t rt_scene_num_units(const rt_scene* s) { return s ? s->dev.n_units : 0; }
 int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
     if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_units: NULL argument");
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_units needs a committed host-only scene");
-    if (n_floats != s->flat.units.size()) return fail(RT_ERR_INVALID, "rt_scene_get_units: size mismatch");
-    std::memcpy(out, s->flat.units.data(), n_floats * sizeof(float));
+    if (n_floats != s->flat.n_units() * 4) return fail(RT_ERR_INVALID, "rt_scene_get_units: size mismatch");
+    std::memcpy(out, s->flat.units.data(), n_floats * sizeof(float));   // (without the end units)
     return RT_OK;
 }
 

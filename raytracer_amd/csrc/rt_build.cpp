@@ -368,7 +368,11 @@ void pack_units(FlatScene& out) {
     }
     unit_of[n] = (uint32_t)u;
     if (u > ORD_RIGHT_MASK) out.ordered_ok = false;
-    out.units.assign((size_t)u * 4, 0.0f);
+    out.units.assign((size_t)(u + UNITS_END) * 4, 0.0f);
+    {
+        const uint32_t end_word = TAG_END << TAG_SHIFT;     // the end units: only the tag word matters
+        std::memcpy(&out.units[(size_t)u * 4 + 3], &end_word, 4);
+    }
     for (size_t i = 0; i < n; i++) {
         const float* e = &out.entries[i * ENTRY_FLOATS];
         float* d = &out.units[(size_t)unit_of[i] * 4];
@@ -430,13 +434,15 @@ struct OctantCopy {
 }  // namespace
 
 void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out) {
-    out.assign(n_units * 4 * 8, 0u);
+    const size_t stride = n_units + UNITS_END;               // units per copy
+    out.assign(stride * 4 * 8, 0u);
     std::vector<std::thread> workers;
     for (uint32_t oct = 0; oct < 8; oct++)
         workers.emplace_back([=, &out]() {
-            OctantCopy c{units, out.data() + (size_t)oct * n_units * 4, (uint32_t)(oct * n_units), oct};
+            OctantCopy c{units, out.data() + (size_t)oct * stride * 4, (uint32_t)(oct * stride), oct};
             uint32_t pos = 0;
             for (uint32_t u = 0; u < n_units; u = c.end_of(u)) pos = c.emit(u, pos);   // top-level entries in order
+            c.dst[(size_t)pos * 4 + 3] = TAG_END << TAG_SHIFT;                          // this copy's end units
         });
     for (std::thread& w : workers) w.join();
 }

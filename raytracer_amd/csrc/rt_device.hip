@@ -162,13 +162,15 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
-    uint32_t n_ent = n_ent_;                   // OCT: the end of the lane's copy
-    if (OCT) { r.i = n_ent_ * octant_of(dx, dy, dz); n_ent = r.i + n_ent_; }
-    // A lane without a (further) entry holds TAG_END in the tag word of `a`: whether a lane stands at
-    // a box or at a primitive is then one compare of that word, whose lane mask is the ballot.
+    if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(dx, dy, dz);   // the lane's copy
+    // The unit array ends with two TAG_END units (every copy of it does, in the octant form), which
+    // is where the last entries' links lead: a lane fetches its next entry unconditionally, and a
+    // lane that has walked off the end -- or never had a ray -- holds TAG_END in the tag word of `a`.
+    // Whether a lane stands at a box or at a primitive is one compare of that word, whose lane mask
+    // is the ballot.
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
     float4 a = ended, b = ended;
-    if (valid && n_ent_ > 0) { a = ent[r.i]; b = ent[r.i + 1]; }
+    if (valid) { a = ent[r.i]; b = ent[r.i + 1]; }
     for (;;) {
         const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
         const bool at_box = tag == TAG_BOX;
@@ -180,8 +182,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
-            else a.w = ended.w;
+            a = ent[r.i]; b = ent[r.i + 1];    // (behind the last entry: the TAG_END units)
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
@@ -195,8 +196,7 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
                     sphere_step(a, b, r, t_min);
                     r.i = r.i + 2;
                 }
-                if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
-                else a.w = ended.w;
+                a = ent[r.i]; b = ent[r.i + 1];
             }
         }
     }
@@ -768,7 +768,6 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     LaneRay r;
     lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
-    uint32_t n_ent = n_ent_;                   // OCT: the end of the copy the lane's ray walks
     bool has_ray = false;
     uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
     // (a lane without an entry to visit holds TAG_END in the tag word of `a`, as in closest_hit)
@@ -802,8 +801,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
                     slot = f2u(ra.w);
                     has_ray = true;
-                    if (OCT) { r.i = n_ent_ * octant_of(rb.x, rb.y, rb.z); n_ent = r.i + n_ent_; }
-                    if (n_ent_ > 0) { a = ent[r.i]; b = ent[r.i + 1]; }
+                    if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
+                    a = ent[r.i]; b = ent[r.i + 1];
                 }
                 next = min(n, next + n_idle);
                 continue;
@@ -817,8 +816,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
         if (at_box) {
             if (COUNT) cnt.box++;
             r.i = box_step(a, b, r, t_min);
-            if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
-            else a.w = end_word;
+            a = ent[r.i]; b = ent[r.i + 1];    // (behind the last entry: the TAG_END units)
         }
         if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
             if (at_prim) {
@@ -832,8 +830,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     sphere_step(a, b, r, t_min);
                     r.i = r.i + 2;
                 }
-                if (r.i < n_ent) { a = ent[r.i]; b = ent[r.i + 1]; }
-                else a.w = end_word;
+                a = ent[r.i]; b = ent[r.i + 1];
             }
         }
     }
@@ -1139,7 +1136,7 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
     if (SWEEP == 4 || SWEEP == 6) {
         const float4* src = (const float4*)sc.units;
         float4* dst = (float4*)lds_stack;
-        for (uint32_t i = threadIdx.x; i < sc.n_units; i += RT_LDS_BLOCK) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_units + UNITS_END; i += RT_LDS_BLOCK) dst[i] = src[i];
         __syncthreads();                       // before any wave of the workgroup may leave
     }
     if (seg >= g.n_seg) return;
@@ -1307,7 +1304,7 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
     hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
     if (sc.lds_walk && !sc.ordered && !sc.sweep && !sc.octant) {
-        const size_t bytes = (size_t)sc.n_units * 16u;
+        const size_t bytes = (size_t)(sc.n_units + UNITS_END) * 16u;
 #define RT_PATH_LDS(SWP)                                                                                \
         hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
                            bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \

@@ -41,6 +41,9 @@ constexpr uint32_t ORD_RIGHT_MASK = (1u << 29) - 1u;
 constexpr uint32_t ORD_AXIS_SHIFT = 29;
 constexpr uint32_t ORD_FIRST_LOWER = 1u << 31;
 constexpr uint32_t ORDERED_MAX_DEPTH = 64;   // 4 waves x 64 lanes x 64 slots x 4 B = 64 KB of LDS per workgroup
+// the unit array (and each of its octant copies) is followed by this many TAG_END units, where the
+// links of the last entries lead: the per-lane walks fetch their next entry unconditionally
+constexpr uint32_t UNITS_END = 2;
 constexpr uint32_t KIND_SHIFT = 28;
 constexpr uint32_t MAT_MASK = (1u << KIND_SHIFT) - 1u;
 constexpr uint32_t PRIM_BACKFACE = 1u << 31;       // flag in the compact hit record
@@ -58,7 +61,7 @@ struct FlatScene {
     // sphere is the first two float4 of its entry, a triangle the first three; skip links and child
     // links count units.
     std::vector<float> units;
-    size_t n_units() const { return units.size() / 4; }
+    size_t n_units() const { return units.size() / 4 - UNITS_END; }   // without the end units
     uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
     bool ordered_ok = false;           // box entries carry the child links of the ordered walk
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
@@ -80,8 +83,8 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
                              int root_kind, int build_mode, FlatScene& out);
 
 // The unit array once per direction octant (bit k of the octant: the ray's direction is negative
-// along axis k), copy o at units [o * n_units, (o + 1) * n_units) with links that count from the
-// start of the whole array: in copy o the two children of every box are stored nearer child first
+// along axis k), copy o at units [o * (n_units + UNITS_END), ...) with its own end units and links
+// that count from the start of the whole array: in copy o the two children of every box are stored nearer child first
 // for the rays of that octant (by the axis and order annotate_children recorded), so the plain
 // skip-link walk meets them front to back.  `units` must carry the child links (ordered_ok).
 void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out);   // units as 32-bit words
@@ -91,7 +94,7 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
     const void* entries;      // float4[4 * n_entries] (+ the TAG_END entry): the wave sweep's form
-    const void* units;        // float4[n_units]: the per-lane walks' form
+    const void* units;        // float4[n_units + UNITS_END]: the per-lane walks' form
     const void* prim_geo;     // float4[n_prims]
     const uint32_t* prim_meta;
     const void* materials;    // float4[2 * n_mats]
@@ -107,7 +110,7 @@ struct DevScene {
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
     uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
     uint32_t refill;          // per-lane walk in the fused kernel: idle lanes that trigger a refill from the segment (0: off)
-    const void* units_oct;    // float4[8 * n_units]: the unit array once per direction octant (octant walk)
+    const void* units_oct;    // float4[8 * (n_units + UNITS_END)]: the unit array once per direction octant (octant walk)
     uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
 };
 
