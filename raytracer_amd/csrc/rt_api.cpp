@@ -603,7 +603,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     }
     // Forms of the closest-hit loop that give the same frame bit for bit but whose speed depends on
     // the scene are timed against each other on the scene's first render, on a probe batch of the
-    // frame itself (<= 4 Mi paths, written to the pipeline's buffers only); the scene keeps the winner.
+    // frame itself (written to the pipeline's buffers only); the scene keeps the winner.
     //  - small scenes (AUTO only): wave sweep against the per-lane walk out of LDS.  How much of the
     //    scene a ray visits decides (a closed room: the sweep, by 1.5x; scattered objects under a
     //    sky: the walk, by 1.2-1.5x).
@@ -643,33 +643,55 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
             g.tiles_x = tiles_x;
             g.tile_base = 0;
-            const size_t nt = std::min<size_t>(tiles_per_batch, 4096);
+            // Small scenes (sweep against the walk out of LDS) are cheap and the two forms lie close
+            // together, so the probe is a whole batch of the frame, cut into the segments the form
+            // really gets (the sweep fills its groups of 128 rays worse from short segments).  Big
+            // scenes: at most 4 Mi paths, in segments as long as the real batches' (what the refill
+            // draws on) but not over 512, so that the probe still spreads over every wave slot.
+            const bool whole_batch = s->dev.lds_walk != 0;
+            const size_t nt = whole_batch ? tiles_per_batch : std::min<size_t>(tiles_per_batch, 4096);
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin;
-            g.n_samples = (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, ((size_t)4 << 20) / (nt * 64)));
+            g.n_samples = whole_batch ? samples_per_batch
+                                      : (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, ((size_t)4 << 20) / (nt * 64)));
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
-            // segments as long as the real batches' (what the refill draws on), but not over 512, so
-            // that the probe still spreads over every wave slot of the chip
-            g.seg_len = std::min(512u, seg_len_for(tiles_per_batch * 64 * (size_t)samples_per_batch, form_target(s->dev)));
+            g.seg_len = seg_len_for(tiles_per_batch * 64 * (size_t)samples_per_batch, form_target(s->dev));
+            if (!whole_batch) g.seg_len = std::min(512u, g.seg_len);
             g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
+            // (a whole-batch probe runs the way the frame will: one batch on each pipeline at once --
+            // the sweep gains more from a second kernel in flight than the walk out of LDS does)
+            const int probe_pipes = whole_batch ? std::max(1, std::min(n_pipes, 2)) : 1;
+            RenderBuffers rbs[2];
+            for (int k = 0; k < probe_pipes; k++) {
+                Pipe& pk = ctx->pipes[k];
+                rc = ensure_capacity(ctx, pk, g.n_slots, g.n_seg);
+                if (rc) return rc;
+                RenderBuffers& rb = rbs[k];
+                rb.hits = pk.hits.p;
+                for (int q = 0; q < 3; q++) rb.queue[q] = (uint32_t*)pk.queue[q].p;
+                rb.Lbuf = pk.lbuf.p;
+                rb.totals = (Totals*)ctx->totals.p;
+                rb.capacity = pk.capacity;
+                rb.segcnt = (uint32_t*)pk.segcnt.p;
+                rb.qcnt = (uint32_t*)pk.qcnt.p;
+                rb.cur = RayBuffers{pk.rayA[0].p, pk.rayB[0].p, pk.rayC[0].p};
+                rb.next = RayBuffers{pk.rayA[1].p, pk.rayB[1].p, pk.rayC[1].p};
+            }
             Pipe& pp = ctx->pipes[0];
-            rc = ensure_capacity(ctx, pp, g.n_slots, g.n_seg);
-            if (rc) return rc;
-            RenderBuffers rb;
-            rb.hits = pp.hits.p;
-            for (int q = 0; q < 3; q++) rb.queue[q] = (uint32_t*)pp.queue[q].p;
-            rb.Lbuf = pp.lbuf.p;
-            rb.totals = (Totals*)ctx->totals.p;
-            rb.capacity = pp.capacity;
-            rb.segcnt = (uint32_t*)pp.segcnt.p;
-            rb.qcnt = (uint32_t*)pp.qcnt.p;
-            rb.cur = RayBuffers{pp.rayA[0].p, pp.rayB[0].p, pp.rayC[0].p};
-            rb.next = RayBuffers{pp.rayA[1].p, pp.rayB[1].p, pp.rayC[1].p};
             for (int rep = 0; rep < 2; rep++) {            // the second run is the timed one
                 HIP_TRY(hipEventRecord(ctx->ev_begin, pp.stream));
-                if (launch_path(ctx->cfg(0), s->dev, *cam, g, p->seed, rb, p->max_bounces, p->t_min, p->sky_intensity))
-                    return fail(RT_ERR_DEVICE, "path kernel launch failed");
+                for (int k = 1; k < probe_pipes; k++) {
+                    HIP_TRY(hipEventRecord(ctx->ev_fork, pp.stream));
+                    HIP_TRY(hipStreamWaitEvent(ctx->pipes[k].stream, ctx->ev_fork, 0));
+                }
+                for (int k = 0; k < probe_pipes; k++)
+                    if (launch_path(ctx->cfg(k), s->dev, *cam, g, p->seed, rbs[k], p->max_bounces, p->t_min, p->sky_intensity))
+                        return fail(RT_ERR_DEVICE, "path kernel launch failed");
+                for (int k = 1; k < probe_pipes; k++) {
+                    HIP_TRY(hipEventRecord(ctx->pipes[k].joined, ctx->pipes[k].stream));
+                    HIP_TRY(hipStreamWaitEvent(pp.stream, ctx->pipes[k].joined, 0));
+                }
                 HIP_TRY(hipEventRecord(ctx->ev_end, pp.stream));
             }
             HIP_TRY(hipStreamSynchronize(pp.stream));

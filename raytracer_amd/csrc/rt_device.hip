@@ -25,6 +25,26 @@
 
 #include "rt_internal.hpp"
 
+// Two translation units are built from this file.  The kernels of the per-lane walks are compiled
+// without SLP vectorisation (rt_device_walk.hip includes this file with RT_TU_WALK defined and is
+// built with -fno-slp-vectorize): the vectoriser packs pieces of their scalar arithmetic into
+// v_pk_* instructions, which occupy the pipe as long as the two they replace, and pays for it with
+// register shuffles and a dozen more VGPRs (world1 +10 %, thing.obj +17 % without it).  The wave
+// sweep, whose arithmetic is written on 2-vectors, is 10 % faster WITH the vectoriser, so it stays
+// in the default unit together with the kernels that do not depend on the traversal.  Diagnostic
+// builds (-DRT_STAMPS, -DRT_UTIL) and -DRT_SINGLE_TU keep everything in one unit.
+#if defined(RT_STAMPS) || defined(RT_UTIL) || defined(RT_SINGLE_TU)
+#ifndef RT_TU_WALK
+#define RT_HAS_SWEEP 1
+#define RT_HAS_WALK 1
+#endif
+#elif defined(RT_TU_WALK)
+#define RT_HAS_WALK 1
+#else
+#define RT_HAS_SWEEP 1
+#endif
+#if defined(RT_HAS_SWEEP) || defined(RT_HAS_WALK)
+
 namespace rtamd {
 
 #define RT_BLOCK 256   // grid-stride kernels
@@ -681,6 +701,7 @@ __device__ __forceinline__ uint32_t raygen_segment(const rt_camera& cam, const B
     return out;
 }
 
+#ifdef RT_HAS_SWEEP
 __global__ void __launch_bounds__(RT_WAVE)
 k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4* __restrict__ A,
          float4* __restrict__ B, float4* __restrict__ C, uint32_t* __restrict__ segcnt) {
@@ -689,6 +710,8 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
     const uint32_t out = raygen_segment(cam, g, seed_lo, seed_hi, A, B, C, seg * g.seg_len, lane);
     if (lane == 0) segcnt[seg] = out;
 }
+
+#endif  // RT_HAS_SWEEP
 
 // ---------------------------------------------------------------------------------------------
 // trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
@@ -1081,6 +1104,7 @@ __device__ __forceinline__ uint32_t shade_segment(const DevScene& sc, const floa
     return out;
 }
 
+#ifdef RT_HAS_SWEEP
 __global__ void __launch_bounds__(RT_WAVE)
 k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, const uint2* __restrict__ hits, const uint32_t* __restrict__ q0,
@@ -1093,6 +1117,8 @@ k_shade(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
                                        qcnt[g.n_seg + seg], qcnt[2u * g.n_seg + seg], depth, lane);
     if (lane == 0) segcnt_next[seg] = out;
 }
+
+#endif  // RT_HAS_SWEEP
 
 // ---------------------------------------------------------------------------------------------
 // The whole life of a segment's paths in one kernel: raygen, then trace and shade per depth.  A
@@ -1176,6 +1202,7 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
 #endif
 }
 
+#ifdef RT_HAS_SWEEP
 // ---------------------------------------------------------------------------------------------
 // accumulate: per pixel, add the batch's samples in sample order (one owner per pixel: no
 // atomics, fixed summation order).
@@ -1222,6 +1249,8 @@ k_tonemap(const float* __restrict__ accum, float scale, uint32_t* __restrict__ o
     }
 }
 
+#endif  // RT_HAS_SWEEP
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -1233,22 +1262,104 @@ static inline uint32_t grid_for(size_t n, uint32_t cap) {
 }
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? 0 : -1; }
 
-int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
-                     float t_max, void* d_hits, Totals* d_counts, bool count) {
-    if (n == 0) return 0;
-    hipStream_t st = (hipStream_t)cfg.stream;
-    const uint32_t grid = grid_for(n, cfg.grid_cap);
-    const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+// Which unit holds the kernel a scene is traced with: the wave sweep lives in the default unit,
+// every per-lane walk in the unit built without SLP vectorisation.
+static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant; }
+int launch_trace_api_walk(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min, float t_max,
+                          void* d_hits, Totals* d_counts, bool count);
+int launch_trace_walk(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
+                      bool last_depth, float t_min, float sky_intensity, bool count);
+int launch_path_walk(const LaunchCfg&, const DevScene&, const rt_camera&, const BatchGeom&, uint64_t seed,
+                     const RenderBuffers&, uint32_t max_bounces, float t_min, float sky_intensity);
+
 #define RT_TRACE_API(CNT, SWP)                                                                          \
     hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), lds, st, sc, (const float*)d_rays, n, \
                        t_min, t_max, (rt_hit*)d_hits, d_counts)
-    const int mode = sc.octant ? 7 : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0));
-    if (mode == 7) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
-    else if (mode == 3) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
-    else if (mode == 2) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
-    else if (mode == 1) { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
+#define RT_TRACE(CNT, SWP)                                                                              \
+    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
+                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
+                       rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
+                       last_depth ? 1u : 0u, t_min, sky_intensity RT_STAMP_ARG)
+#define RT_PATH(SWP)                                                                                    \
+    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
+                       (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
+#define RT_PATH_LDS(SWP)                                                                                \
+    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
+                       bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
+                       sky_intensity RT_STAMP_ARG)
+#ifdef RT_STAMPS
+static uint32_t stamped_launches = 0;
+#endif
+
+static inline PathBuffers path_buffers(const RenderBuffers& rb) {
+    PathBuffers pb;
+    pb.A0 = (float4*)rb.cur.A; pb.B0 = (float4*)rb.cur.B; pb.C0 = (float4*)rb.cur.C;
+    pb.A1 = (float4*)rb.next.A; pb.B1 = (float4*)rb.next.B; pb.C1 = (float4*)rb.next.C;
+    pb.hits = (uint2*)rb.hits;
+    pb.q0 = rb.queue[0]; pb.q1 = rb.queue[1]; pb.q2 = rb.queue[2];
+    pb.Lbuf = (float4*)rb.Lbuf;
+    pb.segcnt = rb.segcnt;
+    pb.totals = rb.totals;
+    return pb;
+}
+
+#ifdef RT_HAS_WALK
+int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
+                          float t_max, void* d_hits, Totals* d_counts, bool count) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t grid = grid_for(n, cfg.grid_cap);
+    const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+    if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
+    else if (sc.ordered) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
-#undef RT_TRACE_API
+    return check_launch();
+}
+
+int launch_trace_walk(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
+                      uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
+    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+#ifdef RT_STAMPS
+    const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
+#endif
+    if (sc.octant) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
+    else if (sc.ordered) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
+    else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
+    return check_launch();
+}
+
+int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
+                     const RenderBuffers& rb, uint32_t max_bounces, float t_min, float sky_intensity) {
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const PathBuffers pb = path_buffers(rb);
+    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+#ifdef RT_STAMPS
+    const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
+#endif
+    if (sc.lds_walk && !sc.ordered && !sc.octant) {
+        const size_t bytes = (size_t)(sc.n_units + UNITS_END) * 16u;
+        if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
+        return check_launch();
+    }
+    if (sc.octant) { if (sc.refill) RT_PATH(8); else RT_PATH(7); }
+    else if (sc.ordered) RT_PATH(3);
+    else if (sc.refill) RT_PATH(5);
+    else RT_PATH(0);
+    return check_launch();
+}
+#endif  // RT_HAS_WALK
+
+#ifdef RT_HAS_SWEEP
+int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
+                     float t_max, void* d_hits, Totals* d_counts, bool count) {
+    if (n == 0) return 0;
+    if (!uses_sweep_kernels(sc)) return launch_trace_api_walk(cfg, sc, d_rays, n, t_min, t_max, d_hits, d_counts, count);
+    hipStream_t st = (hipStream_t)cfg.stream;
+    const uint32_t grid = grid_for(n, cfg.grid_cap);
+    const size_t lds = 0;
+    if (sc.has_spheres) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
+    else { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
     return check_launch();
 }
 
@@ -1262,67 +1373,28 @@ int launch_raygen(const LaunchCfg& cfg, const rt_camera& cam, const BatchGeom& g
 
 int launch_trace(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom& g, const RenderBuffers& rb,
                  uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
+    if (!uses_sweep_kernels(sc)) return launch_trace_walk(cfg, sc, g, rb, depth, last_depth, t_min, sky_intensity, count);
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
-    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
-#define RT_TRACE(CNT, SWP)                                                                              \
-    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
-                       (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
-                       rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
-                       last_depth ? 1u : 0u, t_min, sky_intensity RT_STAMP_ARG)
+    const size_t lds = 0;
 #ifdef RT_STAMPS
-    static uint32_t stamped_launches = 0;
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    const int mode = sc.octant ? 7 : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : 0));
-    if (mode == 7) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
-    else if (mode == 3) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
-    else if (mode == 2) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
-    else if (mode == 1) { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
-    else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
-#undef RT_TRACE
+    if (sc.has_spheres) { if (count) RT_TRACE(true, 2); else RT_TRACE(false, 2); }
+    else { if (count) RT_TRACE(true, 1); else RT_TRACE(false, 1); }
     return check_launch();
 }
 
 int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, const BatchGeom& g, uint64_t seed,
                 const RenderBuffers& rb, uint32_t max_bounces, float t_min, float sky_intensity) {
+    if (!uses_sweep_kernels(sc)) return launch_path_walk(cfg, sc, cam, g, seed, rb, max_bounces, t_min, sky_intensity);
     hipStream_t st = (hipStream_t)cfg.stream;
-    PathBuffers pb;
-    pb.A0 = (float4*)rb.cur.A; pb.B0 = (float4*)rb.cur.B; pb.C0 = (float4*)rb.cur.C;
-    pb.A1 = (float4*)rb.next.A; pb.B1 = (float4*)rb.next.B; pb.C1 = (float4*)rb.next.C;
-    pb.hits = (uint2*)rb.hits;
-    pb.q0 = rb.queue[0]; pb.q1 = rb.queue[1]; pb.q2 = rb.queue[2];
-    pb.Lbuf = (float4*)rb.Lbuf;
-    pb.segcnt = rb.segcnt;
-    pb.totals = rb.totals;
-    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+    const PathBuffers pb = path_buffers(rb);
+    const size_t lds = 0;
 #ifdef RT_STAMPS
-    static uint32_t stamped = 0;
-    const uint32_t stamp_slot = stamped < STAMP_SLOTS ? stamped++ : 0xFFFFFFFFu;
+    const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-#define RT_PATH(SWP)                                                                                    \
-    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
-                       (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
-    if (sc.lds_walk && !sc.ordered && !sc.sweep && !sc.octant) {
-        const size_t bytes = (size_t)(sc.n_units + UNITS_END) * 16u;
-#define RT_PATH_LDS(SWP)                                                                                \
-        hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
-                           bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
-                           sky_intensity RT_STAMP_ARG)
-        if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
-#undef RT_PATH_LDS
-        return check_launch();
-    }
-    const int mode = sc.octant ? (sc.refill ? 8 : 7)
-                               : (sc.ordered ? 3 : (sc.sweep ? (sc.has_spheres ? 2 : 1) : (sc.refill ? 5 : 0)));
-    if (mode == 8) RT_PATH(8);
-    else if (mode == 7) RT_PATH(7);
-    else if (mode == 5) RT_PATH(5);
-    else if (mode == 3) RT_PATH(3);
-    else if (mode == 2) RT_PATH(2);
-    else if (mode == 1) RT_PATH(1);
-    else RT_PATH(0);
-#undef RT_PATH
+    if (sc.has_spheres) RT_PATH(2); else RT_PATH(1);
     return check_launch();
 }
 
@@ -1365,5 +1437,8 @@ int launch_tonemap(const LaunchCfg& cfg, const void* d_accum, uint32_t spp, void
                        (const float*)d_accum, 1.0f / (float)spp, (uint32_t*)d_out, npix);
     return check_launch();
 }
+#endif  // RT_HAS_SWEEP
 
 }  // namespace rtamd
+
+#endif  // this unit holds kernels
