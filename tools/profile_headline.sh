@@ -3,7 +3,9 @@
 #   bash tools/profile_headline.sh <out dir>
 # 1. rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu` (and of --staged);
 # 2. three --pmc passes (SQ counters, FETCH_SIZE, WRITE_SIZE: separate runs) of
-#    `python3 bench.py --no-cpu --steps 1 --warmup 0`, summarised per kernel by tools/pmc_summary.py.
+#    `python3 bench.py --no-cpu --steps 1 --warmup 0 --traversal sweep` (the form the unprofiled run
+#    takes: counters serialise kernels, which would tip the first render's timing of the candidate
+#    forms the other way), summarised per kernel by tools/pmc_summary.py.
 set -e
 out=${1:-gpurun_out/headline}
 root=$PWD
@@ -17,7 +19,7 @@ for pass in sq fetch write; do
         fetch) ctr="FETCH_SIZE";;
         write) ctr="WRITE_SIZE";;
     esac
-    timeout -s KILL 300 rocprofv3 --pmc $ctr -d $out/$pass -o p --output-format csv -- python3 bench.py --no-cpu --steps 1 --warmup 0 > $out/$pass.json 2> $out/$pass.err
+    timeout -s KILL 300 rocprofv3 --pmc $ctr -d $out/$pass -o p --output-format csv -- python3 bench.py --no-cpu --steps 1 --warmup 0 --traversal sweep > $out/$pass.json 2> $out/$pass.err
     python3 tools/pmc_summary.py $out/$pass/p_counter_collection.csv > $out/pmc_$pass.txt
 done
 cp $out/stats/s_kernel_stats.csv $out/kernel_stats.csv
