@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,12 @@ int make_world(rt_context* ctx, rt_world** out, F&& ctor) {
         w->renderer.reset(new GpuRenderer(ctx, ctor()));
         *out = w.release();
         return RT_OK;
+    } catch (const StatusError& e) {           // a failed rt_scene_* call: its own status
+        rt_internal_set_error(e.what());
+        return e.status;
+    } catch (const std::bad_alloc&) {
+        rt_internal_set_error("rt_world_create: out of host memory");
+        return RT_ERR_NOMEM;
     } catch (const std::exception& e) {
         return host_fail(e.what());
     } catch (...) {
@@ -100,7 +107,7 @@ size_t rt_world_num_objects(const rt_world* w) { return w ? w->renderer->descrip
 int rt_world_object_info(const rt_world* w, size_t i, size_t* count) {
     if (!w || !count || i >= w->renderer->description().objects.size()) return host_fail("rt_world_object_info: bad argument");
     const auto& o = w->renderer->description().objects[i];
-    *count = o.is_mesh ? o.tris.size() : 1;
+    *count = o.is_mesh ? o.n_tris : 1;
     return o.is_mesh ? 1 : 0;
 }
 int rt_world_get_sphere(const rt_world* w, size_t i, rt_sphere* out) {
@@ -111,7 +118,12 @@ int rt_world_get_sphere(const rt_world* w, size_t i, rt_sphere* out) {
 int rt_world_get_mesh(const rt_world* w, size_t i, rt_triangle* out) {
     RT_HOST_GUARD_BEGIN
     if (!w || !out || i >= w->renderer->description().objects.size()) return host_fail("rt_world_get_mesh: bad argument");
-    const auto& t = w->renderer->description().objects[i].tris;
+    const auto& o = w->renderer->description().objects[i];
+    if (o.released) {
+        rt_internal_set_error("rt_world_get_mesh: the host copy of this mesh was released after the commit");
+        return RT_ERR_STATE;
+    }
+    const auto& t = o.tris;
     std::memcpy(out, t.data(), t.size() * sizeof(rt_triangle));
     return RT_OK;
     RT_HOST_GUARD_END("rt_world_get_mesh")

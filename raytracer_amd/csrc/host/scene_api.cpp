@@ -262,6 +262,7 @@ struct Describer {
             std::vector<uint32_t> local(m->materials.size());
             for (size_t i = 0; i < local.size(); i++) local[i] = material(m->materials[i]);
             o.tris.resize(m->triangles.size());
+            o.n_tris = o.tris.size();
             for (size_t i = 0; i < o.tris.size(); i++) {
                 const Triangle& t = m->triangles[i];
                 rt_triangle& r = o.tris[i];
@@ -300,7 +301,7 @@ SceneDescription describe(const World& world) {
 // ---- GpuRenderer ----------------------------------------------------------------------------
 GpuRenderer::GpuRenderer(rt_context* ctx, World world) : ctx_(ctx), world_(std::move(world)) {
     desc_ = describe(world_);
-    auto ok = [](int rc) { if (rc != RT_OK) throw std::runtime_error(rt_last_error()); };
+    auto ok = [](int rc) { if (rc != RT_OK) throw StatusError(rc, rt_last_error()); };
     ok(rt_scene_create(ctx, &scene_));
     try {
         ok(rt_scene_set_materials(scene_, desc_.materials.data(), desc_.materials.size()));
@@ -316,13 +317,15 @@ GpuRenderer::GpuRenderer(rt_context* ctx, World world) : ctx_(ctx), world_(std::
         throw;
     }
     // the reference keeps its triangles alive inside the Mesh; the GPU copy is what renders, so
-    // the host copies of big meshes are dropped once committed
+    // the host copies of big meshes are dropped once committed (a host-only world keeps them: it
+    // exists to be inspected)
+    if (!ctx) return;
     if (Bvh* b = dynamic_cast<Bvh*>(world_.hittable.get()))
         for (HittableBox& o : b->objects)
             if (Mesh* m = dynamic_cast<Mesh*>(o.get()))
                 if (m->triangles.size() > (1u << 20)) { m->triangles.clear(); m->triangles.shrink_to_fit(); }
     for (SceneDescription::Object& o : desc_.objects)
-        if (o.tris.size() > (1u << 20)) { o.tris.clear(); o.tris.shrink_to_fit(); }
+        if (o.tris.size() > (1u << 20)) { o.tris.clear(); o.tris.shrink_to_fit(); o.released = true; }
 }
 
 GpuRenderer::~GpuRenderer() {

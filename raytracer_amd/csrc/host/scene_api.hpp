@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -156,12 +157,19 @@ World create_soup(uint64_t n_tris, uint32_t grid, uint32_t seed);
 // What the C ABI needs to know about a World.
 struct SceneDescription {
     std::vector<rt_material> materials;
-    struct Object { bool is_mesh; rt_sphere sphere; std::vector<rt_triangle> tris; };
+    // n_tris stays the mesh's triangle count after `tris` has been released (big meshes, once committed)
+    struct Object { bool is_mesh; rt_sphere sphere; std::vector<rt_triangle> tris; size_t n_tris = 0; bool released = false; };
     std::vector<Object> objects;
     int root_kind = RT_ROOT_BVH;
 };
 // Throws std::runtime_error for what the ABI cannot express (nested containers, transforms).
 SceneDescription describe(const World& world);
+
+// a failed rt_* call inside the host layer: carries the call's rt_status and message
+struct StatusError : std::runtime_error {
+    int status;
+    StatusError(int s, const std::string& msg) : std::runtime_error(msg), status(s) {}
+};
 
 // The drop-in for render(): owns the committed GPU scene of one World.
 class GpuRenderer {

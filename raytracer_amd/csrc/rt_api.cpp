@@ -155,6 +155,9 @@ int ensure_capacity(rt_context* ctx, Pipe& pp, size_t paths, size_t n_seg) {
     HIP_TRY(pp.segcnt.ensure((size_t)(MAX_DEPTH + 1) * n_seg * sizeof(uint32_t)));
     HIP_TRY(pp.qcnt.ensure((size_t)3 * n_seg * sizeof(uint32_t)));
     if (paths <= pp.capacity) return RT_OK;
+    // a grow that fails part-way leaves some buffers released: the pipeline then holds nothing
+    // until every buffer has been resized
+    pp.capacity = 0;
     for (int k = 0; k < 2; k++) {
         HIP_TRY(pp.rayA[k].ensure(paths * 16));
         HIP_TRY(pp.rayB[k].ensure(paths * 16));

@@ -158,12 +158,15 @@ struct Builder {
         }
         return b;
     }
-    void fill_mesh_range_sah(uint32_t* idx, size_t n, size_t at, int fork_levels) {
+    // Binned SAH can peel one triangle off per level on a skewed mesh; below SAH_MAX_DEPTH levels the
+    // nodes are halved instead, so the recursion (and every later walk over the tree) stays shallow.
+    static constexpr int SAH_MAX_DEPTH = 40;
+    void fill_mesh_range_sah(uint32_t* idx, size_t n, size_t at, int fork_levels, int depth = 0) {
         if (n == 0) return;
         if (n == 1) { write_triangle(at, idx[0]); return; }
         write_box(at, padded_box(idx, n), at + mesh_entries(n));
         size_t half = n / 2;
-        if (n > 2) {
+        if (n > 2 && depth < SAH_MAX_DEPTH) {
             constexpr int BINS = 16;
             const float* cen = tri_cen.data();
             float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -221,12 +224,12 @@ struct Builder {
         }
         const size_t left_at = at + 1, right_at = left_at + mesh_entries(half);
         if (fork_levels > 0 && n >= 65536) {
-            std::thread left([=]() { fill_mesh_range_sah(idx, half, left_at, fork_levels - 1); });
-            fill_mesh_range_sah(idx + half, n - half, right_at, fork_levels - 1);
+            std::thread left([=]() { fill_mesh_range_sah(idx, half, left_at, fork_levels - 1, depth + 1); });
+            fill_mesh_range_sah(idx + half, n - half, right_at, fork_levels - 1, depth + 1);
             left.join();
         } else {
-            fill_mesh_range_sah(idx, half, left_at, 0);
-            fill_mesh_range_sah(idx + half, n - half, right_at, 0);
+            fill_mesh_range_sah(idx, half, left_at, 0, depth + 1);
+            fill_mesh_range_sah(idx + half, n - half, right_at, 0, depth + 1);
         }
     }
 
@@ -354,7 +357,7 @@ void annotate_children(FlatScene& out) {
 // the last word of a triangle's third unit holds the distance to the entry behind it, and it is
 // four where that entry is a box or a sphere that would otherwise start at an odd unit, so that
 // every box and sphere (32 bytes) starts at a multiple of 32 bytes and never straddles a line.
-void pack_units(FlatScene& out) {
+bool pack_units(FlatScene& out) {       // false: the unit links do not fit 30 bits
     const size_t n = out.n_entries();
     auto word = [&](size_t i, int k) { uint32_t u; std::memcpy(&u, &out.entries[i * ENTRY_FLOATS + k], 4); return u; };
     auto tag_of = [&](size_t i) { return word(i, 3) >> TAG_SHIFT; };
@@ -366,6 +369,7 @@ void pack_units(FlatScene& out) {
         unit_of[i] = (uint32_t)u;
         u += tag_of(i) == TAG_TRI ? 3 : 2;
     }
+    if (u + UNITS_END > SKIP_MASK) return false;
     unit_of[n] = (uint32_t)u;
     if (u > ORD_RIGHT_MASK) out.ordered_ok = false;
     out.units.assign((size_t)(u + UNITS_END) * 4, 0.0f);
@@ -389,6 +393,7 @@ void pack_units(FlatScene& out) {
             std::memcpy(&d[11], &stride, 4);
         }
     }
+    return true;
 }
 
 }  // namespace
@@ -517,7 +522,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     }
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
     annotate_children(out);
-    pack_units(out);
+    if (!pack_units(out)) return "scene too large for 30-bit unit links";
     return std::string();
 }
 

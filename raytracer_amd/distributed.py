@@ -30,9 +30,14 @@ def init_from_env(backend=None, force=False):
 
 
 def reduce_to_root(accum):
-    """Sum the per-rank accumulation buffers into rank 0's (in place).  No-op without a process group."""
+    """Sum the per-rank accumulation buffers into rank 0's (in place).  No-op without a process group.
+    Returns when the sum is complete in the buffer: under RCCL dist.reduce() only orders torch's
+    current stream behind the collective, and the renderer's kernels (tonemap included) run on the
+    context's own stream, which knows nothing of torch's."""
     if dist.is_available() and dist.is_initialized():
         dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if accum.is_cuda:
+            torch.cuda.current_stream(accum.device).synchronize()
     return accum
 
 

@@ -81,6 +81,7 @@ def main(argv=None):
     accum, st = render_frame(world, width, height, args.spp, args.depth, rank, world_size, device, args.seed)
     if rank == 0:
         packed = torch.zeros(height * width, dtype=torch.int32, device=device)
+        torch.cuda.current_stream().synchronize()          # the fill runs on torch's stream, the tonemap on the context's
         ctx.tonemap_device(accum.data_ptr(), args.spp, packed.data_ptr(), height * width)
         write_ppm(args.out, packed, width, height)
         print(f"Finished in {time.perf_counter() - t0:.2f}s: {args.scene} {width}x{height}, {args.spp} spp on "
