@@ -90,6 +90,7 @@ struct rt_context {
     uint32_t grid_cap = 2048;
     Pipe pipes[MAX_PIPES];
     DeviceBuffer totals, scratch_in, scratch_out;
+    DeviceBuffer frame_in, frame_out;   // rt_render / rt_tonemap: device copies of the caller's host buffers
     uint32_t wave_target = 8192, wave_target_sweep = 8192;
     int n_pipes = 2;
     hipEvent_t ev_fork = nullptr;
@@ -347,6 +348,15 @@ static int apply_traversal(rt_scene* s, int mode) {
         }
         s->dev.units_oct = s->d_units_oct.p;
     }
+    {   // experiment knobs, read whenever the kernel form is (re)chosen.  RT_PRIM_WAIT: lanes that must
+        // wait at primitives before their routine runs (best of {1 .. 64} measured on the sphere and OBJ
+        // scenes, from memory and out of LDS alike: 8; 2 .. 12 lie within 3 %).  RT_REFILL: idle lanes
+        // that trigger a refill in the fused kernel's per-lane walk (pins that form; 0 pins the plain one).
+        const char* e = std::getenv("RT_PRIM_WAIT");
+        s->env_prim_wait = e ? (uint32_t)std::max(1, std::atoi(e)) : 0u;
+        e = std::getenv("RT_REFILL");
+        s->env_refill = e ? (uint32_t)std::min(64, std::max(0, std::atoi(e))) : 0u;
+    }
     s->dev.octant = mode == RT_TRAVERSAL_OCTANT ? 1u : 0u;
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
     s->auto_tuned = false;
@@ -436,16 +446,6 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
     s->dev.lds_walk = (s->dev.n_units > 0 && ((size_t)s->dev.n_units + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
-    {   // lanes that must wait at primitives before their routine runs: best of {1 .. 64} measured
-        // on the sphere and OBJ scenes, from memory and out of LDS alike (2 .. 12 lie within 3 %)
-        const char* e = getenv("RT_PRIM_WAIT");
-        s->env_prim_wait = e ? (uint32_t)std::max(1, atoi(e)) : 0u;
-        s->dev.prim_wait = e ? s->env_prim_wait : 8u;
-    }
-    {
-        const char* e = getenv("RT_REFILL");
-        s->env_refill = e ? (uint32_t)std::min(64, std::max(0, atoi(e))) : 0u;
-    }
     rc = apply_traversal(s, s->traversal);
     if (rc) return rc;
     // the host copies of the geometry are no longer needed
@@ -901,7 +901,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_render_params* p, floa
     int rc = set_device(ctx);
     if (rc) return rc;
     const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
-    DeviceBuffer d;
+    DeviceBuffer& d = ctx->frame_in;           // kept by the context: progressive renders call this per step
     HIP_TRY(d.ensure(bytes));
     HIP_TRY(hipMemcpyAsync(d.p, accum_rgb, bytes, hipMemcpyHostToDevice, ctx->stream));
     rt_stats local;
@@ -930,7 +930,7 @@ int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* 
     if (npix == 0) return RT_OK;
     int rc = set_device(ctx);
     if (rc) return rc;
-    DeviceBuffer in, o;
+    DeviceBuffer &in = ctx->frame_in, &o = ctx->frame_out;
     HIP_TRY(in.ensure(npix * 12));
     HIP_TRY(o.ensure(npix * 4));
     HIP_TRY(hipMemcpyAsync(in.p, accum_rgb, npix * 12, hipMemcpyHostToDevice, ctx->stream));

@@ -1,0 +1,155 @@
+"""The bandwidth stress workload: a synthetic triangle soup plus a sphere field, traced and rendered
+at depth 16 from a tree that does not fit the caches.
+
+4 M triangles give a 12 M-entry array (0.32 GB in the per-lane walks' 16-byte units: past the 4 MB
+of an XCD's L2 and the 256 MB Infinity Cache, so the lower levels stream from HBM), which the oracle
+still builds and traces in seconds.  The generator (host layer) describes the scene once; the same
+description goes to the oracle.  RT_TEST_SOUP_TRIS overrides the size.
+
+* closest hits of >= 1 M rays (the oracle's recorded camera and bounce rays at depth 16, plus random
+  rays through the volume): primitive id exact and t bit-exact on the per-lane walk; on the opt-in
+  near-first walks (ordered, octant) and the opt-in SAH tree t bit-exact and the primitive equal
+  except on exact ties, whose count is printed;
+* a frame at depth 16 against the oracle's frame within the Monte-Carlo bound of test_gpu_render;
+  the fused kernel (plain and with idle lanes refilled) against the staged launches bit for bit;
+* the full workload (10 M triangles, 3840 x 2160, 256 spp, depth 16): the frame twice is the same
+  frame bit for bit, its paths are counted exactly, and mean radiance and rays per path agree with
+  the oracle's render of the same scene at 480 x 270 and 4 spp (the largest oracle render that
+  keeps this test to a couple of minutes; both are unbiased estimates of the same integrals)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_hits_equal, random_rays
+
+pytestmark = pytest.mark.gpu
+
+N_TRIS = int(os.environ.get("RT_TEST_SOUP_TRIS", "4000000"))
+CAMERA = ((260.0, -260.0, 160.0), (0.0, 0.0, 40.0), (0.0, 0.0, 1.0), 40.0, 0.0, 200.0)   # create_soup's
+
+
+def _oracle_of(ob, world):
+    return ob.Scene.from_description(world.materials(), world.objects(), world.root_kind, camera=CAMERA, sky=world.sky)
+
+
+@pytest.fixture(scope="module")
+def soup(rt, ob, ctx):
+    host = rt.World.soup(None, N_TRIS, grid=64, seed=12345)        # host-only: keeps the triangles
+    osc = _oracle_of(ob, host)
+    host.close()
+    world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
+    assert world.scene.num_prims == N_TRIS + 64 * 64 + 1
+    rays = np.concatenate([osc.record_rays(1280, 720, 1, 16, cap=1_000_000),
+                           random_rays(ob, 21, 250_000, -100.0, 100.0)])
+    rays["o"][-250_000:, 2] = np.abs(rays["o"][-250_000:, 2])
+    want, st = osc.trace(rays, nthreads=16)
+    print(f"soup of {N_TRIS} triangles: {world.scene.num_entries} entries, {len(rays)} rays, "
+          f"{(want['prim_id'] != ob.MISS).mean():.3f} hit, {st['box_tests'] / len(rays):.1f} box tests per ray")
+    yield world, osc, rays, want
+    world.close()
+
+
+def test_soup_closest_hits_match_oracle(rt, ob, ctx, soup):
+    world, osc, rays, want = soup
+    assert len(rays) >= 1_000_000 and (want["prim_id"] != ob.MISS).sum() > 100_000
+    world.scene.set_traversal(rt.TRAVERSAL_PER_LANE)
+    assert_hits_equal(world.scene.trace(rays), want)
+    world.scene.set_traversal(rt.TRAVERSAL_AUTO)
+    assert_hits_equal(world.scene.trace(rays[:200_000]), want[:200_000])
+
+
+def _same_up_to_ties(rt, got, want, label):
+    nan = np.isnan(want["t"])
+    assert np.array_equal(got["prim_id"] == rt.MISS, want["prim_id"] == rt.MISS)
+    hit = (want["prim_id"] != rt.MISS) & ~nan
+    assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), f"{label}: t differs"
+    ties = int((got["prim_id"] != want["prim_id"]).sum())
+    print(f"{label}: {len(want)} rays, t bit-identical, {ties} exact ties resolved to another primitive")
+    assert ties <= 1e-4 * len(want)
+
+
+@pytest.mark.parametrize("walk", ["ordered", "octant"])
+def test_soup_near_first_walks(rt, ob, ctx, soup, walk):
+    world, osc, rays, want = soup
+    world.scene.set_traversal(rt.TRAVERSAL_ORDERED if walk == "ordered" else rt.TRAVERSAL_OCTANT)
+    try:
+        _same_up_to_ties(rt, world.scene.trace(rays), want, f"{walk} walk")
+    finally:
+        world.scene.set_traversal(rt.TRAVERSAL_AUTO)
+
+
+def test_soup_sah_tree(rt, ob, ctx, soup):
+    _, osc, rays, want = soup
+    rt.set_default_build(rt.BUILD_SAH)
+    try:
+        world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
+    finally:
+        rt.set_default_build(rt.BUILD_REFERENCE)
+    for mode, label in ((rt.TRAVERSAL_PER_LANE, "SAH tree, per-lane walk"), (rt.TRAVERSAL_OCTANT, "SAH tree, octant walk")):
+        world.scene.set_traversal(mode)
+        _same_up_to_ties(rt, world.scene.trace(rays), want, label)
+    world.close()
+
+
+def test_soup_frame_depth16(rt, ob, ctx, soup, monkeypatch):
+    world, osc, _, _ = soup
+    w, h, spp, depth = 160, 90, 32, 16
+    cam = world.camera(w, h)
+    a, _, st_a = osc.render(w, h, spp, depth, seed_offset=0, nthreads=16)
+    b, _, _ = osc.render(w, h, spp, depth, seed_offset=7919, nthreads=16)
+    world.scene.set_traversal(rt.TRAVERSAL_AUTO)
+    g, st = world.scene.render(cam, world.params(w, h, spp, depth))
+    rm = lambda x, y: float(np.sqrt(np.mean((np.minimum(x / spp, 4.0) - np.minimum(y / spp, 4.0)) ** 2)))
+    floor, err = rm(a, b), max(rm(g, a), rm(g, b))
+    print(f"depth-16 frame: rmse {err:.5f} floor {floor:.5f} ratio {err / floor:.4f}; rays per path "
+          f"gpu {st['rays_traced'] / st['paths']:.4f} oracle {st_a['rays'] / st_a['paths']:.4f}")
+    assert np.isfinite(g).all() and st["paths"] == w * h * spp
+    assert err <= 1.10 * floor
+    mean_o = 0.5 * (a.mean() + b.mean())
+    assert abs(g.mean() - mean_o) <= 0.02 * mean_o
+    assert abs(st["rays_traced"] / st["paths"] - st_a["rays"] / st_a["paths"]) < 0.03
+    # the fused kernel's two per-lane forms against the staged launches, bit for bit
+    staged, st0 = world.scene.render(cam, world.params(w, h, spp, depth, flags=rt.RENDER_STAGED))
+    for refill in ("0", "16"):
+        monkeypatch.setenv("RT_REFILL", refill)
+        world.scene.set_traversal(rt.TRAVERSAL_PER_LANE)
+        img, st1 = world.scene.render(cam, world.params(w, h, spp, depth))
+        assert st1["rays_traced"] == st0["rays_traced"]
+        assert np.array_equal(img.view(np.uint32), staged.view(np.uint32))
+    monkeypatch.delenv("RT_REFILL")
+    world.scene.set_traversal(rt.TRAVERSAL_AUTO)
+
+
+def test_soup_full_size_frame(rt, ob, ctx):
+    import bench
+    kind, w, h, spp, depth = bench.WORKLOADS["soup_10m_4k_256"]
+    n = int(os.environ.get("RT_SOUP_TRIS", "10000000"))
+    host = rt.World.soup(None, n, grid=64, seed=12345)
+    osc = _oracle_of(ob, host)
+    host.close()
+    oimg, _, ost = osc.render(480, 270, 4, depth, nthreads=16, want_image=False)
+    del osc
+    world = rt.World.soup(ctx, n, grid=64, seed=12345)
+    cam = world.camera(w, h)
+    accum = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+
+    def render():
+        accum.zero_()
+        torch.cuda.synchronize()
+        st = world.scene.render_device(cam, world.params(w, h, spp, depth), accum.data_ptr())
+        return accum.clone(), st
+
+    frame, st = render()
+    again, st2 = render()
+    assert st["paths"] == w * h * spp and st["rays_traced"] == st2["rays_traced"]
+    assert torch.equal(frame.view(torch.int32), again.view(torch.int32))
+    assert torch.isfinite(frame).all()
+    mean_gpu = float(frame.double().mean()) / spp
+    mean_cpu = float(np.asarray(oimg, dtype=np.float64).mean()) / 4
+    print(f"soup_10m_4k_256: {st['rays_traced']} rays in {st['ms_render']:.0f} ms; mean radiance gpu {mean_gpu:.5f} "
+          f"oracle {mean_cpu:.5f}; rays per path gpu {st['rays_traced'] / st['paths']:.4f} oracle {ost['rays'] / ost['paths']:.4f}")
+    assert abs(mean_gpu - mean_cpu) <= 0.03 * mean_cpu
+    assert abs(st["rays_traced"] / st["paths"] - ost["rays"] / ost["paths"]) < 0.03
+    world.close()
