@@ -195,6 +195,23 @@ int rt_trace(rt_scene* scene, const rt_ray* rays, size_t n, float t_min, float t
 int rt_trace_device(rt_scene* scene, const void* d_rays, size_t n, float t_min, float t_max,
                     void* d_hits, uint64_t* counts);
 
+/* No counterpart in the reference.  rt_trace_device() with visit counts for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): it calls no hipMalloc / hipFree or other allocating routine, and it does not wait for
+ * the stream -- the work is queued on rt_context_stream() and the caller orders itself after it
+ * (rt_context_synchronize(), or an event on that stream).  The per-workgroup partial counts that
+ * rt_trace_device() keeps in a buffer it allocates live here in a static device array of the
+ * library (512 KB on every GPU the library runs on, held until the process ends): one 32-byte
+ * record per workgroup of 256 rays, hence at most RT_TRACE_STATIC_MAX_RAYS rays per call (more:
+ * RT_ERR_INVALID).  d_counts is DEVICE memory for three uint64_t (box, triangle, sphere tests) and
+ * is overwritten.  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU
+ * (two contexts, or two host threads) race; calls queued one after the other on the context's
+ * stream do not.  Nothing in the array has to start at zero (a call overwrites the records it
+ * reads).  Hits are those of rt_trace_device(). */
+#define RT_TRACE_STATIC_MAX_RAYS 4194304u
+int rt_trace_device_static(rt_scene* scene, const void* d_rays, size_t n, float t_min, float t_max,
+                           void* d_hits, void* d_counts);
+
 /* ---- render: render() and its tile closure (main.rs:319-416) --------------------------- */
 /* Adds, for every pixel of the rectangle, the sum over the sample range of the path radiance
  * (ray_color, main.rs:40-67) to accum_rgb (width*height*3 floats, linear, row-major, host

@@ -31,6 +31,7 @@ TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSA
 BUILD_REFERENCE, BUILD_SAH = 0, 1
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
+TRACE_STATIC_MAX_RAYS = 4194304
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
 material_dt = np.dtype([("kind", "<u4"), ("rgb", "<f4", 3), ("param", "<f4"), ("flags", "<u4")])
@@ -103,6 +104,7 @@ def _load():
         "rt_scene_get_units": (i32, [vp, vp, sz]),
         "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
         "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
+        "rt_trace_device_static": (i32, [vp, vp, sz, f32, f32, vp, vp]),
         "rt_render": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
         "rt_render_device": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
         "rt_tonemap": (i32, [vp, vp, u32, vp, sz]),
@@ -145,7 +147,7 @@ ABI_SYMBOLS = [
     "rt_scene_set_traversal", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
     "rt_scene_get_units", "rt_trace",
-    "rt_trace_device", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
+    "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
 HOST_SYMBOLS = [
     "rt_world_create_world1", "rt_world_create_world2", "rt_world_create_cornell_box",
@@ -303,6 +305,11 @@ class Scene:
         counts = (C.c_uint64 * 3)() if count else None
         _check(lib.rt_trace_device(self.h, d_rays, n, t_min, t_max, d_hits, counts))
         return tuple(counts) if count else None
+
+    def trace_device_static(self, d_rays, n, d_hits, d_counts, t_min=0.001, t_max=np.inf):
+        """rt_trace_device_static: allocates nothing, queues on the context's stream and returns;
+        d_counts is device memory for three uint64 (box, triangle, sphere tests)."""
+        _check(lib.rt_trace_device_static(self.h, d_rays, n, t_min, t_max, d_hits, d_counts))
 
     @staticmethod
     def params(width, height, spp, max_bounces, sky, rect=None, samples=None, seed=DEFAULT_SEED,

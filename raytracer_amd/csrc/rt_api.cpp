@@ -90,7 +90,9 @@ struct rt_context {
     uint32_t grid_cap = 2048;
     Pipe pipes[MAX_PIPES];
     DeviceBuffer totals, scratch_in, scratch_out;
+    DeviceBuffer trace_partials;        // rt_trace_device with counts: one record per workgroup
     DeviceBuffer frame_in, frame_out;   // rt_render / rt_tonemap: device copies of the caller's host buffers
+    void* static_scratch = nullptr;     // this device's copy of the library's static array (rt_trace_device_static)
     uint32_t wave_target = 8192, wave_target_sweep = 8192;
     int n_pipes = 2;
     hipEvent_t ev_fork = nullptr;
@@ -229,6 +231,8 @@ int rt_context_create(int device_id, rt_context** out) {
     HIP_TRY(hipEventCreate(&ctx->ev_begin));
     HIP_TRY(hipEventCreate(&ctx->ev_end));
     if (const char* e = std::getenv("RT_PIPES")) ctx->n_pipes = std::min(MAX_PIPES, std::max(1, std::atoi(e)));
+    if (static_scratch_address(device_id, &ctx->static_scratch))
+        return fail(RT_ERR_DEVICE, "rt_context_create: hipGetSymbolAddress of the static scratch array failed");
     *out = ctx.release();
     return RT_OK;
     RT_GUARD_END("rt_context_create")
@@ -488,23 +492,47 @@ int rt_trace_device(rt_scene* s, const void* d_rays, size_t n, float t_min, floa
     rt_context* ctx = s->ctx;
     int rc = set_device(ctx);
     if (rc) return rc;
+    const uint32_t grid = trace_api_grid(ctx->cfg(), n);
     if (counts) {
         HIP_TRY(ctx->totals.ensure(sizeof(Totals)));
-        HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), ctx->stream));
+        HIP_TRY(ctx->trace_partials.ensure((size_t)std::max(grid, 1u) * sizeof(Totals)));
     }
-    if (launch_trace_api(ctx->cfg(), s->dev, d_rays, n, t_min, t_max, d_hits, (Totals*)ctx->totals.p,
-                         counts != nullptr))
+    if (launch_trace_api(ctx->cfg(), s->dev, d_rays, n, t_min, t_max, d_hits, (Totals*)ctx->trace_partials.p,
+                         counts != nullptr, grid, ctx->totals.p))
         return fail(RT_ERR_DEVICE, "rt_trace_device: kernel launch failed");
     if (counts) {
-        Totals t;
-        HIP_TRY(hipMemcpyAsync(&t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t t[3];
+        HIP_TRY(hipMemcpyAsync(t, ctx->totals.p, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        counts[0] = t.box; counts[1] = t.tri; counts[2] = t.sph;
+        counts[0] = t[0]; counts[1] = t[1]; counts[2] = t[2];
     } else {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     return RT_OK;
     RT_GUARD_END("rt_trace_device")
+}
+
+// rt_trace_device with visit counts for callers that cannot allocate: the per-workgroup records live
+// in the library's static device array and the totals go to device memory of the caller's.  Calls
+// nothing that allocates and does not wait for the stream.
+int rt_trace_device_static(rt_scene* s, const void* d_rays, size_t n, float t_min, float t_max, void* d_hits,
+                           void* d_counts) {
+    if (!s || !d_counts || (n && (!d_rays || !d_hits))) return fail(RT_ERR_INVALID, "rt_trace_device_static: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    if (n > (size_t)RT_TRACE_STATIC_MAX_RAYS)
+        return fail(RT_ERR_INVALID, "rt_trace_device_static: more than RT_TRACE_STATIC_MAX_RAYS (4194304) rays in one call; "
+                                    "split the batch or use rt_trace_device");
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    if (!ctx->static_scratch) return fail(RT_ERR_STATE, "rt_trace_device_static: the context has no scratch address");
+    static_assert((uint64_t)TRACE_STATIC_MAX_BLOCKS * TRACE_STATIC_BLOCK_RAYS == RT_TRACE_STATIC_MAX_RAYS, "limit");
+    const uint32_t grid = (uint32_t)((n + TRACE_STATIC_BLOCK_RAYS - 1) / TRACE_STATIC_BLOCK_RAYS);   // one record each
+    if (launch_trace_api(ctx->cfg(), s->dev, d_rays, n, t_min, t_max, d_hits, (Totals*)ctx->static_scratch, true, grid,
+                         d_counts))
+        return fail(RT_ERR_DEVICE, "rt_trace_device_static: kernel launch failed");
+    return RT_OK;
 }
 
 int rt_trace(rt_scene* s, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out) {

@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #ifdef RT_STAMPS
 #include <stdio.h>
 #include <stdlib.h>
@@ -542,7 +543,7 @@ extern __shared__ uint32_t lds_stack[];
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
-            rt_hit* __restrict__ out, Totals* totals) {
+            rt_hit* __restrict__ out, Totals* partials) {
     const float4* ent = (const float4*)sc.entries;
     Counts cnt{0, 0, 0};
     if (SWEEP == 1 || SWEEP == 2) {
@@ -588,11 +589,51 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
         }
     }
     if (COUNT) {
-        atomicAdd(&totals->box, (unsigned long long)cnt.box);
-        atomicAdd(&totals->tri, (unsigned long long)cnt.tri);
-        atomicAdd(&totals->sph, (unsigned long long)cnt.sph);
+        // The workgroup's visit counts go to its own record of `partials` (every workgroup writes
+        // its record, zero or not, so the array needs no clearing; k_sum_partials adds the records
+        // up): wave reduction, then the workgroup's waves through LDS.  No atomics.
+        __shared__ unsigned long long red[RT_BLOCK / 64][3];
+        unsigned long long b = cnt.box, t = cnt.tri, sp = cnt.sph;
+        for (int off = 32; off > 0; off >>= 1) {
+            b += __shfl_down(b, off); t += __shfl_down(t, off); sp += __shfl_down(sp, off);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            red[threadIdx.x >> 6][0] = b; red[threadIdx.x >> 6][1] = t; red[threadIdx.x >> 6][2] = sp;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            Totals tot{0ull, 0ull, 0ull, 0ull};
+            for (uint32_t w = 0; w < RT_BLOCK / 64; w++) { tot.box += red[w][0]; tot.tri += red[w][1]; tot.sph += red[w][2]; }
+            partials[blockIdx.x] = tot;
+        }
     }
 }
+
+#ifdef RT_HAS_SWEEP
+// box / triangle / sphere totals of a traced batch: the sum of the workgroups' records, written
+// (not added) to out3[0..2]
+__global__ void __launch_bounds__(RT_BLOCK)
+k_sum_partials(const Totals* __restrict__ partials, uint32_t n_records, unsigned long long* __restrict__ out3) {
+    __shared__ unsigned long long red[RT_BLOCK / 64][3];
+    unsigned long long b = 0, t = 0, sp = 0;
+    for (uint32_t i = threadIdx.x; i < n_records; i += RT_BLOCK) {
+        const Totals p = partials[i];
+        b += p.box; t += p.tri; sp += p.sph;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        b += __shfl_down(b, off); t += __shfl_down(t, off); sp += __shfl_down(sp, off);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        red[threadIdx.x >> 6][0] = b; red[threadIdx.x >> 6][1] = t; red[threadIdx.x >> 6][2] = sp;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long v = 0;
+        for (uint32_t w = 0; w < RT_BLOCK / 64; w++) v += red[w][threadIdx.x];
+        out3[threadIdx.x] = v;
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wave-level compaction: ballot + lane prefix.  `count` is wave-uniform.
@@ -1266,7 +1307,7 @@ static inline int check_launch() { return hipGetLastError() == hipSuccess ? 0 : 
 // every per-lane walk in the unit built without SLP vectorisation.
 static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant; }
 int launch_trace_api_walk(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min, float t_max,
-                          void* d_hits, Totals* d_counts, bool count);
+                          void* d_hits, Totals* d_counts, bool count, uint32_t grid);
 int launch_trace_walk(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
                       bool last_depth, float t_min, float sky_intensity, bool count);
 int launch_path_walk(const LaunchCfg&, const DevScene&, const rt_camera&, const BatchGeom&, uint64_t seed,
@@ -1305,9 +1346,8 @@ static inline PathBuffers path_buffers(const RenderBuffers& rb) {
 
 #ifdef RT_HAS_WALK
 int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
-                          float t_max, void* d_hits, Totals* d_counts, bool count) {
+                          float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const uint32_t grid = grid_for(n, cfg.grid_cap);
     const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
     if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
     else if (sc.ordered) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
@@ -1351,16 +1391,49 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #endif  // RT_HAS_WALK
 
 #ifdef RT_HAS_SWEEP
+uint32_t trace_api_grid(const LaunchCfg& cfg, size_t n) { return grid_for(n, cfg.grid_cap); }
+
 int launch_trace_api(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
-                     float t_max, void* d_hits, Totals* d_counts, bool count) {
-    if (n == 0) return 0;
-    if (!uses_sweep_kernels(sc)) return launch_trace_api_walk(cfg, sc, d_rays, n, t_min, t_max, d_hits, d_counts, count);
+                     float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid, void* d_out3) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const uint32_t grid = grid_for(n, cfg.grid_cap);
-    const size_t lds = 0;
-    if (sc.has_spheres) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
-    else { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
+    if (n == 0) grid = 0;
+    if (n != 0) {
+        if (!uses_sweep_kernels(sc)) {
+            if (launch_trace_api_walk(cfg, sc, d_rays, n, t_min, t_max, d_hits, d_counts, count, grid)) return -1;
+        } else {
+            const size_t lds = 0;
+            if (sc.has_spheres) { if (count) RT_TRACE_API(true, 2); else RT_TRACE_API(false, 2); }
+            else { if (count) RT_TRACE_API(true, 1); else RT_TRACE_API(false, 1); }
+            if (check_launch()) return -1;
+        }
+    }
+    if (count)
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(RT_BLOCK), 0, st, (const Totals*)d_counts, grid,
+                           (unsigned long long*)d_out3);
     return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scratch of rt_trace_device_static(): one 32-byte record of partial visit counts per workgroup of
+// the closest-hit kernel, in a device array the library owns for the life of the process (every
+// GPU holds its own copy at its own address).  In host code `scratch` is only a handle for
+// hipGetSymbolAddress(); the kernels are handed the address that call returns.
+// ---------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned long long scratch[(size_t)TRACE_STATIC_MAX_BLOCKS * 4];
+
+int static_scratch_address(int device, void** out) {
+    constexpr int MAX_DEVICES = 64;
+    static void* known[MAX_DEVICES] = {};
+    static std::mutex lock;
+    if (device < 0 || device >= MAX_DEVICES || !out) return -1;
+    std::lock_guard<std::mutex> guard(lock);
+    if (!known[device]) {                      // first context on this device (which is current)
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return -1;
+        known[device] = p;
+    }
+    *out = known[device];
+    return 0;
 }
 
 int launch_raygen(const LaunchCfg& cfg, const rt_camera& cam, const BatchGeom& g, uint64_t seed,

@@ -173,8 +173,17 @@ struct LaunchCfg {
 };
 
 // kernels' host-side launchers (rt_device.hip)
+// closest hit of a ray batch on `grid` workgroups; with `count` every workgroup writes its visit
+// counts to its record of d_partials (>= grid records) and their sum goes to d_out3[0..2]
+// (box, triangle, sphere tests; 64-bit)
+uint32_t trace_api_grid(const LaunchCfg&, size_t n);
 int launch_trace_api(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min,
-                     float t_max, void* d_hits, Totals* d_counts, bool count);
+                     float t_max, void* d_hits, Totals* d_partials, bool count, uint32_t grid, void* d_out3);
+// rt_trace_device_static(): workgroup records of the library's static device array, and that
+// array's address on `device` (which must be the current device)
+constexpr uint32_t TRACE_STATIC_MAX_BLOCKS = 16384;
+constexpr uint32_t TRACE_STATIC_BLOCK_RAYS = 256;
+int static_scratch_address(int device, void** out);
 int launch_raygen(const LaunchCfg&, const rt_camera&, const BatchGeom&, uint64_t seed, const RenderBuffers&);
 int launch_trace(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
                  bool last_depth, float t_min, float sky_intensity, bool count);

@@ -25,6 +25,7 @@ pub const RT_RENDER_PROFILE: u32 = 1;
 pub const RT_RENDER_COUNT_VISITS: u32 = 2;
 pub const RT_RENDER_STAGED: u32 = 4;
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
+pub const RT_TRACE_STATIC_MAX_RAYS: u32 = 4194304;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct rt_material { pub kind: u32, pub rgb: [f32; 3], pub param: f32, pub flags: u32 }
@@ -87,6 +88,8 @@ extern "C" {
     pub fn rt_trace(scene: *mut rt_scene, rays: *const rt_ray, n: usize, t_min: f32, t_max: f32, out: *mut rt_hit) -> c_int;
     pub fn rt_trace_device(scene: *mut rt_scene, d_rays: *const c_void, n: usize, t_min: f32, t_max: f32,
                            d_hits: *mut c_void, counts: *mut u64) -> c_int;
+    pub fn rt_trace_device_static(scene: *mut rt_scene, d_rays: *const c_void, n: usize, t_min: f32, t_max: f32,
+                                  d_hits: *mut c_void, d_counts: *mut c_void) -> c_int;
     pub fn rt_render(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
                      accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
