@@ -2,15 +2,19 @@
 """Benchmark of the hot path: Mrays/s of the wavefront path tracer on the Cornell box
 (cornell_box_plane.obj, 1024x1024, 1024 spp, max depth 6), whole job over N GPUs.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W
+      one process: a multi-GPU context over GPUs 0 .. N-1 (rt_context_create_multi), the scene built
+      once and uploaded to every GPU, rt_render_multi_device() per step (every GPU renders its share
+      on a host thread of its own, one RCCL sum-reduce to GPU 0).  N = 1 takes the same path.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+      one process per GPU: every rank renders rt_partition(N, rank) with rt_render_device(), then
+      torch.distributed.reduce (RCCL) combines the buffers on rank 0.
 
-A step is one full render of the frame: every rank renders its share (interleaved row bands x
-a sample range), then one RCCL sum-reduce combines the accumulation buffers on rank 0.  Scene
-build, BVH upload and OBJ parsing are outside the timed region.  1 ray = 1 closest-hit query.
-Rank 0 prints ONE JSON line.
+A step is one full render of the frame.  Scene build, BVH upload and OBJ parsing are outside the
+timed region.  1 ray = 1 closest-hit query.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,9 +29,9 @@ sys.path.insert(0, ROOT)
 
 import raytracer_amd as rt                                     # noqa: E402
 from raytracer_amd import distributed as D                     # noqa: E402
-from raytracer_amd.partition import partition                  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, GB/s
+N_SIMDS = 1024                 # 256 CUs x 4
 WORKLOADS = {
     # name: (constructor, width, height, spp, max depth)
     "cornell_plane_1024_1k": ("cornell_plane", 1024, 1024, 1024, 6),
@@ -36,6 +40,8 @@ WORKLOADS = {
     "cornell_full_512_64": ("cornell", 512, 512, 64, 8),
     "soup_10m_4k_256": ("soup", 3840, 2160, 256, 16),
 }
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_workloads.json")
+KERNEL_SOURCES = ("rt_device.hip", "rt_device_walk.hip", "rt_internal.hpp", "rt_api.cpp", "rt_build.cpp", "Makefile")
 
 
 def make_world(ctx, kind):
@@ -67,30 +73,102 @@ def trace_bytes_per_ray(n_box, n_tri, n_sph):
     return 32.0 * n_box + 36.0 * n_tri + 16.0 * n_sph + 32.0 + 8.0 + 4.0
 
 
-def measured_traffic(key="hbm_bytes_per_launch"):
-    """HBM bytes per launch of the per-batch kernel (or another figure) from the committed PMC
-    passes (rocprofv3 cannot run inside this process); None when the file is absent."""
+def kernel_source_hash():
+    """Content hash of the sources the kernels are built from (what a PMC record was measured on)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracer_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(workload, build):
+    """Per-ray hardware counts of this workload's per-batch kernel from the committed rocprofv3 PMC
+    passes (rocprofv3 cannot run inside this process): HBM bytes per ray ((2*FETCH_SIZE + WRITE_SIZE)
+    KiB, the gfx950 correction for 16-byte-per-lane streams), vector instructions per ray, the clock the
+    chip held.  They are properties of the kernel and the workload, so multiplied by the rate measured
+    in THIS run they give this run's HBM and issue rates.  None when there is no record."""
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)["k_path"][key]
+        with open(PMC_FILE) as f:
+            rec = json.load(f)["records"].get(f"{workload}/{build}")
     except (OSError, KeyError, ValueError):
         return None
+    if rec is not None:
+        rec = dict(rec, stale=rec.get("source_hash") != kernel_source_hash())
+    return rec
+
+
+def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray, tests, extra):
+    """The bound of the dominant kernel as a fraction <= 1.  Two candidates, both from measured
+    counts: HBM (PMC bytes per ray x measured rays/s against the 8 TB/s peak) and vector-instruction
+    issue (PMC instructions per ray x measured rays/s, priced at the SIMD cycles per instruction this
+    part sustains with 8 waves per SIMD, tools/valu_rate.hip: 2.1 plain, 3.07 packed f32).  The bound
+    is the larger fraction.  The algorithmic rate of the scope table's per-ray formula is reported
+    beside it: it exceeds the HBM peak when the flattened tree is served from the caches."""
+    out = {"kernel": extra.pop("kernel"), "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "GB/s": round(algo_gbs, 1) if algo_gbs else None,
+                                                         "of_hbm_peak": round(algo_gbs / (HBM_PEAK_GBS * n_gpus), 4) if algo_gbs else None,
+                                                         "tests_per_ray": tests}}
+    rec = pmc_record(workload, build)
+    if rec is None:
+        out.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": None, "traffic": None,
+                    "note": f"no PMC record for {workload}/{build} in profiles/pmc_workloads.json: only the algorithmic rate is known"})
+        out.update(extra)
+        return out
+    per_gpu = rays_per_s / n_gpus
+    hbm_gbs = rec["hbm_bytes_per_ray"] * per_gpu / 1e9
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS
+    cyc = rec["simd_cycles_per_valu_inst"]
+    issue_rate = rec["valu_insts_per_ray"] * per_gpu / (N_SIMDS * rec["clock_ghz"] * 1e9)    # per SIMD cycle
+    issue_peak = 1.0 / cyc
+    issue_frac = issue_rate / issue_peak
+    out["hbm"] = {"achieved_GB/s": round(hbm_gbs, 1), "peak_GB/s": HBM_PEAK_GBS, "frac": round(hbm_frac, 4),
+                  "bytes_per_ray": round(rec["hbm_bytes_per_ray"], 1)}
+    out["valu_issue"] = {"achieved_inst_per_simd_cycle": round(issue_rate, 4), "peak_inst_per_simd_cycle": round(issue_peak, 4),
+                         "frac": round(issue_frac, 4), "insts_per_ray": round(rec["valu_insts_per_ray"], 1),
+                         "active_lanes_per_inst": rec.get("active_lanes"), "clock_ghz": rec["clock_ghz"]}
+    if hbm_frac >= issue_frac:
+        out.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(hbm_frac, 1.0), 4)})
+    else:
+        out.update({"bound": "valu_issue", "achieved": round(issue_rate, 4), "peak": round(issue_peak, 4),
+                    "unit": "vector instructions per SIMD cycle", "frac": round(min(issue_frac, 1.0), 4)})
+    out["traffic"] = int(rec["hbm_bytes_per_ray"] * extra.get("rays_per_launch", 0)) or None
+    out["traffic_unit"] = "HBM bytes per launch of the dominant kernel: PMC bytes per ray x this run's rays per launch"
+    out["pmc"] = {"file": "profiles/pmc_workloads.json", "profiled_form": rec.get("form"), "this_run_form": form,
+                  "git_sha": rec.get("git_sha"), "source_hash": rec.get("source_hash"), "stale": rec["stale"],
+                  "per_gpu": n_gpus > 1}
+    if rec["stale"] or (rec.get("form") and rec.get("form") != form):
+        out["note"] = "the PMC record was taken on other kernel sources or another kernel form than this run's: re-run tools/profile_workloads.sh"
+    out.update(extra)
+    return out
+
+
+def host_threads():
+    """Threads for the CPU leg: every hardware thread this process may run on (its affinity mask),
+    capped by OMP_NUM_THREADS where the machine's operator sets one (the GPU boxes grant a job a
+    16-thread share of a much larger host and export it that way)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    omp = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    return max(1, min(n, omp) if omp > 0 else n)
 
 
 def cpu_baseline(kind, width, height, depth, budget_s, gpu_render):
     """The oracle's tile-per-task renderer on the host cores, on a bounded sample of the workload
     (same scene and resolution, fewer samples per pixel)."""
     from oracle import binding as ob
-    path = os.path.join(rt.ASSET_DIR, "cornell_box_plane.obj")
     if kind == "cornell_plane":
-        osc = ob.Scene.cornell_box(path)
+        osc = ob.Scene.cornell_box(os.path.join(rt.ASSET_DIR, "cornell_box_plane.obj"))
     elif kind == "cornell":
         osc = ob.Scene.cornell_box(os.path.join(rt.ASSET_DIR, "cornell_box.obj"))
     elif kind == "world1":
         osc = ob.Scene.world1()
-    else:
+    elif kind == "world2_glass":
         osc = ob.Scene.world2(os.path.join(rt.ASSET_DIR, "thing.obj"), 1)
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    else:
+        return None                            # (the soup has no oracle constructor; its tests mirror the description)
+    threads = host_threads()
     # calibrate on 1 spp, then pick the spp that fills the budget
     _, _, st = osc.render(width, height, 1, depth, nthreads=threads, want_image=False)
     spp = int(max(1, min(64, budget_s / max(st["seconds"], 1e-3))))
@@ -101,8 +179,8 @@ def cpu_baseline(kind, width, height, depth, budget_s, gpu_render):
     # and gives the baseline's second data point)
     acc2, _, st10 = osc.render(width, height, spp, depth, seed_offset=7919, nthreads=10, want_image=False)
     gpu = gpu_render(spp)
-    rm = lambda a, b: float(np.sqrt(np.mean((np.minimum(a, clip * spp) / spp - np.minimum(b, clip * spp) / spp) ** 2)))
     clip = 4.0
+    rm = lambda a, b: float(np.sqrt(np.mean((np.minimum(a, clip * spp) / spp - np.minimum(b, clip * spp) / spp) ** 2)))
     tm = lambda a: np.minimum(np.sqrt(np.maximum(a / spp, 0.0)), 1.0)          # main.rs:369-373 before the 8-bit pack
     rt_ = lambda a, b: float(np.sqrt(np.mean((tm(a) - tm(b)) ** 2)))
     image = {"spp": spp, "rmse_gpu_vs_oracle": round(rm(gpu, acc), 5), "rmse_oracle_vs_oracle": round(rm(acc2, acc), 5),
@@ -110,8 +188,14 @@ def cpu_baseline(kind, width, height, depth, budget_s, gpu_render):
              "tonemapped_rmse_oracle_vs_oracle": round(rt_(acc2, acc), 5),
              "clip": clip, "note": "linear per-pixel mean radiance (values clipped at 4 to tame fireflies) and "
                                    "tonemapped [0,1] values; bound used by the tests: gpu <= 1.10 x oracle-vs-oracle"}
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
     return {
         "value": round(st["rays"] / st["seconds"] / 1e6, 3), "unit": "Mrays/s", "cores": threads,
+        "host": {"cpus_visible": os.cpu_count(), "cpus_in_affinity_mask": affinity,
+                 "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS")},
         "value_10_threads": round(st10["rays"] / st10["seconds"] / 1e6, 3),
         "kind": "port",
         "sample": f"{kind} {width}x{height}, {spp} spp of the workload's samples, depth {depth}, "
@@ -131,8 +215,10 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debugging)")
     ap.add_argument("--size", default="", help="override WxH (debugging)")
     ap.add_argument("--emulate", default="", help="r/N: render rank r's share of an N-rank job on this one GPU (debugging)")
+    ap.add_argument("--share-gpus", action="store_true",
+                    help="without torchrun: let the --gpus workers share the GPUs that exist (worker i on GPU i %% count; tests)")
     ap.add_argument("--backend", default=os.environ.get("RT_DIST_BACKEND", ""),
-                    help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
+                    help="torch.distributed backend under torchrun (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--build", choices=["reference", "sah"], default="reference",
@@ -145,12 +231,30 @@ def main():
     ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered", "octant"], default="auto")
     args = ap.parse_args()
 
-    rank, world, local = D.init_from_env(args.backend or None, force=args.force_dist)
-    grouped = world > 1 or args.force_dist
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if local >= torch.cuda.device_count():      # several ranks on one GPU (tests only)
-        local = local % max(torch.cuda.device_count(), 1)
+    # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 on
+    # their own (RCCL prints a version banner when its first communicator is made) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    # Two ways to N GPUs.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank of
+    # N and drives one GPU.  Started plainly it drives all N GPUs itself through one context.
+    per_process = "WORLD_SIZE" in os.environ or args.force_dist
+    if per_process:
+        rank, world, local = D.init_from_env(args.backend or None, force=args.force_dist)
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        if local >= torch.cuda.device_count():  # several ranks on one GPU (tests only)
+            local = local % max(torch.cuda.device_count(), 1)
+        devices = None
+    else:
+        rank, world, local = 0, args.gpus, 0
+        have = torch.cuda.device_count()
+        if args.gpus < 1 or (args.gpus > have and not args.share_gpus):
+            raise SystemExit(f"--gpus {args.gpus} but {have} GPU(s) visible")
+        devices = [i % max(have, 1) for i in range(args.gpus)]
+        local = devices[0]
+    grouped = per_process and (world > 1 or args.force_dist)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     kind, width, height, spp, depth = WORKLOADS[args.workload]
@@ -159,7 +263,7 @@ def main():
     if args.size:
         width, height = (int(v) for v in args.size.lower().split("x"))
 
-    ctx = rt.Context(local)
+    ctx = rt.Context(local) if per_process else rt.Context(devices=devices)
     rt.set_default_build(rt.BUILD_SAH if args.build == "sah" else rt.BUILD_REFERENCE)
     t0 = time.time()
     wld = make_world(ctx, kind)
@@ -168,21 +272,29 @@ def main():
                              "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,
                              "octant": rt.TRAVERSAL_OCTANT}[args.traversal])
     cam = wld.camera(width, height)
-    bands, samples = partition(width, height, spp, world, rank)
-    if args.emulate:
-        er, en = (int(v) for v in args.emulate.split("/"))
-        bands, samples = partition(width, height, spp, en, er)
     accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
 
-    def render(flags, smp):
-        p = wld.params(width, height, spp, depth, samples=smp, flags=flags, max_paths=args.max_paths, bands=bands)
-        return wld.scene.render_device(cam, p, accum.data_ptr())
+    def job(flags, samples=None, n_spp=None):
+        return wld.params(width, height, n_spp or spp, depth, samples=samples, flags=flags, max_paths=args.max_paths)
+
+    def share(p):
+        """this process's part of job p"""
+        if args.emulate:
+            er, en = (int(v) for v in args.emulate.split("/"))
+            return rt.partition_params(p, en, er)
+        return rt.partition_params(p, world, rank) if per_process else p
+
+    def render(p):
+        if per_process or args.emulate:
+            return wld.scene.render_device(cam, share(p), accum.data_ptr())
+        return wld.scene.render_multi_device(cam, p, accum.data_ptr())      # every GPU's share + the reduce
 
     def step(flags):
         accum.zero_()
-        torch.cuda.current_stream().synchronize()          # the renderer runs on its own stream
-        st = render(flags, samples)                        # returns after the stream has drained
-        D.reduce_to_root(accum)
+        torch.cuda.current_stream().synchronize()          # the renderer runs on its own streams
+        st = render(job(flags))                            # returns after the streams have drained
+        if per_process:
+            D.reduce_to_root(accum)
         return st
 
     if grouped:
@@ -190,13 +302,16 @@ def main():
         torch.cuda.synchronize()
 
     # per-ray visit counts for the roofline: a counting pass over a few samples (not timed)
-    cs = (samples[0], min(samples[1], samples[0] + 4))
     accum.zero_()
     torch.cuda.synchronize()
-    cst = render(rt.RENDER_COUNT_VISITS, cs)
-    n_box = cst["box_tests"] / cst["rays_traced"]
-    n_tri = cst["tri_tests"] / cst["rays_traced"]
-    n_sph = cst["sph_tests"] / cst["rays_traced"]
+    cst = render(job(rt.RENDER_COUNT_VISITS, samples=(0, min(spp, 4))))
+    if grouped:
+        c = torch.tensor([float(cst[k]) for k in ("box_tests", "tri_tests", "sph_tests", "rays_traced")], dtype=torch.float64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        cst = dict(zip(("box_tests", "tri_tests", "sph_tests", "rays_traced"), c.tolist()))
+    n_box = cst["box_tests"] / max(cst["rays_traced"], 1)
+    n_tri = cst["tri_tests"] / max(cst["rays_traced"], 1)
+    n_sph = cst["sph_tests"] / max(cst["rays_traced"], 1)
 
     timed_flags = rt.RENDER_PROFILE | (rt.RENDER_STAGED if args.staged else 0)
     for _ in range(args.warmup):
@@ -211,40 +326,55 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rays = paths = 0
-    ms_trace = ms_shade = 0.0
+    ms_trace = ms_shade = ms_reduce = 0.0
     launches = 0
+    form = 0
     for _ in range(args.steps):
         st = step(timed_flags)
         rays += st["rays_traced"]
         paths += st["paths"]
         ms_trace += st["ms_trace"]
         ms_shade += st["ms_shade"]
+        ms_reduce += st["ms_reduce"]
         launches += st["trace_launches"]
+        form = st["kernel_form"]
     barrier()
     elapsed = time.perf_counter() - t0
 
-    stats = torch.tensor([elapsed, float(rays), ms_trace, float(launches)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=dev)
     mx = stats.clone()
     sm = stats.clone()
     if grouped:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
     elapsed_max = float(mx[0])
-    total_rays = float(sm[1])
+    total_rays, total_paths = float(sm[1]), float(sm[2])
 
     if rank == 0:
         mean = accum.view(height, width, 3).mean().item() / spp
         value = total_rays / elapsed_max / 1e6
         bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph)
-        # rank 0's dominant kernel: algorithmic bytes of its launches / their summed duration.  Staged:
-        # the closest-hit kernel alone.  Default: the per-batch kernel, which also holds raygen and
-        # shade, so their stream bytes count too (shaded rays >= rays - paths: every ray either ends
-        # its path or is shaded).
-        algo_bytes = bytes_per_ray * rays
+        # the dominant kernel on one GPU (rank 0's, or the slowest GPU's of a one-process job):
+        # algorithmic bytes of its launches / their summed duration.  Staged: the closest-hit kernel
+        # alone.  Default: the per-batch kernel, which also holds raygen and shade, so their stream
+        # bytes count too (shaded rays >= rays - paths: every ray either ends its path or is shaded).
+        n_here = 1 if per_process else world               # GPUs whose rays and launches `rays`, `launches` hold
+        rays_gpu, paths_gpu, launches_gpu = rays / n_here, paths / n_here, launches / n_here
+        algo_bytes = bytes_per_ray * rays_gpu
         if not args.staged:
-            algo_bytes += SHADE_BYTES_PER_RAY * max(rays - paths, 0) + RAYGEN_BYTES_PER_PATH * paths
-        achieved = algo_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
-        headline = args.workload == "cornell_plane_1024_1k" and not (args.spp or args.size)
+            algo_bytes += SHADE_BYTES_PER_RAY * max(rays_gpu - paths_gpu, 0) + RAYGEN_BYTES_PER_PATH * paths_gpu
+        algo_gbs = algo_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
+        form_name = rt.FORM_NAMES[form] if form < len(rt.FORM_NAMES) else str(form)
+        extra = {
+            "kernel": "k_trace (closest hit)" if args.staged else
+                      "k_path (raygen + closest hit and shade per depth, one launch per batch)",
+            "rays_per_launch": int(rays_gpu / max(launches_gpu, 1)),
+            "algorithmic_bytes_per_launch": int(algo_bytes / max(launches_gpu, 1)),
+            "avg_launch_ms": round(ms_trace / max(launches_gpu, 1), 4), "launches": int(launches_gpu),
+            "trace_ms_per_step": round(ms_trace / args.steps, 2),
+            "shade_ms_per_step": round(ms_shade / args.steps, 2),
+        }
+        headline = not (args.spp or args.size or args.emulate or args.staged)
         out = {
             "metric": "Mrays/sec (whole node), Cornell box 1024^2 1k spp",
             "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -252,41 +382,29 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
-                       "build": args.build, "traversal": args.traversal,
-                       "partition": f"rank 0: {bands[0]}-row bands b with b % {bands[1]} == {bands[2]}, "
-                                    f"samples [{samples[0]},{samples[1]})",
-                       "rays_per_step": int(total_rays / args.steps), "paths_per_step": width * height * spp,
+                       "build": args.build, "traversal": args.traversal, "kernel_form": form_name,
+                       "parallelism": (f"{world} processes x 1 GPU, torch.distributed reduce" if per_process else
+                                       f"1 process x {world} GPU(s), rt_render_multi (RCCL reduce in the library)"),
+                       "partition": "rt_partition: interleaved 64-row bands x sample ranges",
+                       "rays_per_step": int(total_rays / args.steps), "paths_per_step": int(total_paths / args.steps),
                        "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3),
+                       "reduce_ms_per_step": round(ms_reduce / args.steps, 3),
                        "accum_sum": float(accum.double().sum().item())},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_trace (closest hit)" if args.staged else "k_path (raygen + closest hit and shade per depth, one launch per batch)",
-                "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                "traffic": measured_traffic() if headline and not args.staged else None,
-                "traffic_unit": "HBM bytes per launch (PMC, profiles/traffic.json)",
-                "valu_pipe_busy": measured_traffic("valu_pipe_busy") if headline and not args.staged else None,
-                "algorithmic_bytes_per_launch": int(algo_bytes / max(launches, 1)),
-                "note": ("frac > 1: the flattened tree of this workload is a few KB and is served from the scalar cache, "
-                         "so most algorithmic bytes never reach HBM (traffic = what does); the kernel is bound by "
-                         "instruction issue, not by HBM (valu_pipe_busy, profiles/r01_pmc_sq.txt)")
-                        if achieved and achieved > HBM_PEAK_GBS else "",
-                "bytes_per_ray": round(bytes_per_ray, 1),
-                "tests_per_ray": {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)},
-                "avg_launch_ms": round(ms_trace / max(launches, 1), 4), "launches": launches,
-                "trace_ms_per_step": round(ms_trace / args.steps, 2),
-                "shade_ms_per_step": round(ms_shade / args.steps, 2),
-            },
+            "roofline": roofline(args.workload if headline or args.spp else None, args.build, form_name, total_rays / elapsed_max,
+                                 world, algo_gbs, bytes_per_ray,
+                                 {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)}, extra),
         }
         if world == 1 and not args.no_cpu:
             def gpu_render(n_spp):
                 accum.zero_()
                 torch.cuda.synchronize()
-                p = wld.params(width, height, n_spp, depth, max_paths=args.max_paths)
-                wld.scene.render_device(cam, p, accum.data_ptr())
+                wld.scene.render_device(cam, job(0, n_spp=n_spp), accum.data_ptr())
                 return accum.view(height, width, 3).cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(kind, width, height, depth, args.cpu_seconds, gpu_render)
-        print(json.dumps(out), flush=True)
+            base = cpu_baseline(kind, width, height, depth, args.cpu_seconds, gpu_render)
+            if base:
+                out["cpu_baseline"] = base
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if grouped:
         dist.barrier()

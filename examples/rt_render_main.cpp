@@ -7,7 +7,12 @@
 // does with a block.
 //
 //   rt_render [--scene cornell|cornell_plane|world1|world2|world2_glass] [--obj FILE] [--size WxH]
-//             [--spp N] [--depth N] [--seed N] [--device N] [--sah] [--progressive] [--out FILE.ppm]
+//             [--spp N] [--depth N] [--seed N] [--device N | --gpus N | --devices a,b,..] [--sah]
+//             [--progressive] [--out FILE.ppm]
+//
+// --gpus N renders on GPUs 0 .. N-1 of the node through one multi-GPU context (the reference's one
+// render() owns all its workers, main.rs:319-336, 443): the scene is built once and uploaded to every
+// GPU, each renders its share of the frame and one RCCL sum-reduce combines them on GPU 0.
 //
 // Plain C++17 against include/rt_abi.h and include/rt_host.h; links librt_amd.so only.
 #include <chrono>
@@ -52,6 +57,7 @@ int main(int argc, char** argv) {
     uint32_t width = IMAGE_SIZE, height = IMAGE_SIZE, spp = SAMPLES_PER_PIXEL, depth = MAX_BOUNCES;
     uint64_t seed = 0x9E3779B97F4A7C15ull;
     int device = 0;
+    std::vector<int> devices;
     bool progressive = false, sah = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -67,6 +73,11 @@ int main(int argc, char** argv) {
         else if (a == "--depth") depth = (uint32_t)std::strtoul(value(), nullptr, 10);
         else if (a == "--seed") seed = std::strtoull(value(), nullptr, 0);
         else if (a == "--device") device = std::atoi(value());
+        else if (a == "--gpus") { const int n = std::atoi(value()); devices.clear(); for (int d = 0; d < n; d++) devices.push_back(d); }
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char* c = value(); *c;) { devices.push_back((int)std::strtol(c, const_cast<char**>(&c), 10)); if (*c == ',') c++; }
+        }
         else if (a == "--progressive") progressive = true;
         else if (a == "--sah") sah = true;
         else { std::fprintf(stderr, "rt_render: unknown argument %s\n", a.c_str()); return 2; }
@@ -74,7 +85,8 @@ int main(int argc, char** argv) {
 
     const auto now = std::chrono::steady_clock::now();          // main.rs:436
     rt_context* ctx = nullptr;
-    if (rt_context_create(device, &ctx)) return die("rt_context_create");
+    if (devices.empty()) { if (rt_context_create(device, &ctx)) return die("rt_context_create"); }
+    else if (rt_context_create_multi((int)devices.size(), devices.data(), &ctx)) return die("rt_context_create_multi");
     if (sah && rt_set_default_build(RT_BUILD_SAH)) return die("rt_set_default_build");
     rt_world* world = nullptr;
     int rc;
@@ -103,7 +115,8 @@ int main(int argc, char** argv) {
     }
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - now).count();
     std::printf("Finished in %.2fs.\n", elapsed);               // main.rs:454 (scene load + tree build + render)
-    std::printf("scene %.3f s, render %.2f ms on the GPU: %llu paths, %llu rays, %.1f Mrays/s%s\n", build_s, st.ms_render,
+    std::printf("scene %.3f s, render %.2f ms on %u GPU(s): %llu paths, %llu rays, %.1f Mrays/s%s\n", build_s, st.ms_render,
+                st.n_devices ? st.n_devices : 1u,
                 (unsigned long long)st.paths, (unsigned long long)st.rays_traced,
                 st.ms_render > 0 ? (double)st.rays_traced / st.ms_render * 1e-3 : 0.0,
                 progressive ? (", " + std::to_string(win.blocks) + " block events").c_str() : "");

@@ -11,9 +11,11 @@
  * Conventions: every call returns 0 on success or a negative rt_status; nothing throws or
  * aborts across the boundary; rt_last_error() gives the message of the last failure on the
  * calling thread.  Inputs are copied; the caller keeps ownership of everything it passes.
- * Calls on one context must be serialised by the caller.  One context drives one GPU: a
- * multi-GPU job runs one process (one context) per GPU and combines the per-GPU accumulation
- * buffers with a single sum-reduce (RCCL), see rt_render_device().
+ * Calls on one context must be serialised by the caller.  A context drives one GPU
+ * (rt_context_create) or several GPUs of one node (rt_context_create_multi): a scene committed on
+ * a multi-GPU context is flattened once and uploaded to every GPU, and rt_render_multi() splits a
+ * frame over them and combines the per-GPU accumulation buffers with one RCCL sum-reduce.  A job of
+ * one process per GPU does the same with rt_partition() + rt_render_device() and its own reduce.
  */
 #ifndef RT_ABI_H
 #define RT_ABI_H
@@ -104,6 +106,12 @@ typedef struct {
                                       raygen to its last bounce; same image bit for bit, slower, but
                                       the stages can be timed apart */
 
+/* which form of the closest-hit loop the render ran (rt_stats.kernel_form): for a scene whose
+ * traversal is RT_TRAVERSAL_AUTO the first render times the forms that apply and keeps the faster,
+ * so two runs may differ here (never in the frame) */
+enum { RT_FORM_SWEEP = 0, RT_FORM_WALK = 1, RT_FORM_WALK_LDS = 2, RT_FORM_WALK_REFILL = 3,
+       RT_FORM_WALK_LDS_REFILL = 4, RT_FORM_ORDERED = 5, RT_FORM_OCTANT = 6, RT_FORM_OCTANT_REFILL = 7 };
+
 typedef struct {
     uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */
     uint64_t paths;          /* camera samples */
@@ -113,10 +121,21 @@ typedef struct {
     double ms_render;        /* wall time of the call on the GPU stream */
     double ms_trace;         /* with RT_RENDER_PROFILE: summed time of those kernels */
     double ms_shade;         /* with RT_RENDER_PROFILE and RT_RENDER_STAGED: summed shade kernel time */
+    double ms_reduce;        /* rt_render_multi: host wall time of the sum-reduce (and the copy to the host) */
+    uint32_t n_devices;      /* GPUs that rendered (1 for rt_render / rt_render_device) */
+    uint32_t kernel_form;    /* RT_FORM_* the render ran (device 0's, for rt_render_multi) */
 } rt_stats;
 
 /* ---- context: stands where ThreadPool::new() does (main.rs:443) ---------------------- */
 int rt_context_create(int device_id, rt_context** out);
+/* One context over n_dev GPUs of this node (render() owns all its workers, main.rs:319-336, 443):
+ * a stream set per GPU, one host thread per GPU during rt_render_multi(), and an RCCL communicator
+ * over the GPUs (ncclCommInitAll).  dev_ids[0] is the root: it receives the reduced frame, and every
+ * single-GPU entry point (rt_trace, rt_render, rt_tonemap, ...) runs on it.  If dev_ids names one GPU
+ * more than once (several workers on one GPU: test rigs) RCCL, which refuses that, is left out
+ * and the buffers, which then all live on that GPU, are added in rank order by a kernel. */
+int rt_context_create_multi(int n_dev, const int* dev_ids, rt_context** out);
+int rt_context_num_devices(const rt_context* ctx);
 void rt_context_destroy(rt_context* ctx);
 const char* rt_last_error(void);
 /* the HIP stream the context launches on (a hipStream_t), for callers that order their own
@@ -224,6 +243,29 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_render_params* par
  * buffers to rank 0. */
 int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
                      void* d_accum_rgb, rt_stats* stats);
+
+/* The share of a job that rank `rank` of `n_ranks` renders (the tile closure's work split,
+ * main.rs:332-336, over GPUs instead of threads): on entry *params describes the whole job
+ * (rectangle, sample range, no bands); on return its sample range and band_* fields describe the
+ * rank's share -- the frame is cut two ways at once, into interleaved bands of 64 rows (the
+ * reference's block height, main.rs:22) and into sample ranges; every (pixel, sample) belongs to
+ * exactly one rank.  With n >= 4 (even) ranks there are two band groups and n / 2 sample ranges,
+ * otherwise one band group and n sample ranges; with fewer samples than ranges the split is by
+ * bands alone, and a rank whose band group holds no band renders nothing (rt_render_device then
+ * returns RT_OK with zero counts). */
+int rt_partition(uint32_t n_ranks, uint32_t rank, rt_render_params* params);
+/* render() on every GPU of a multi-GPU context: GPU r renders rt_partition(n, r) of the job into
+ * its own full-frame buffer (the RNG is keyed by pixel and sample, so the split changes nothing
+ * but f32 summation grouping), then ONE ncclReduce(sum, f32, root = GPU 0) over xGMI combines
+ * them, and the result is added to accum_rgb (host memory, width*height*3; zeroed by the caller
+ * before the first call, like rt_render).  params->band_* must be unset.  Deterministic for a
+ * fixed seed and GPU count.  stats: rays and paths summed over the GPUs, ms_render = the slowest
+ * GPU's, ms_reduce = the reduce.  Works on a one-GPU context too (the same code path). */
+int rt_render_multi(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
+                    float* accum_rgb, rt_stats* stats);
+/* same, adding into a buffer on GPU 0 (the root) of the context */
+int rt_render_multi_device(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
+                           void* d_accum_rgb, rt_stats* stats);
 
 /* ---- tonemap: main.rs:369-373 + rgb_to_u32 (math.rs:112-116) --------------------------- */
 int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out_0rgb, size_t npix);

@@ -31,6 +31,7 @@ TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSA
 BUILD_REFERENCE, BUILD_SAH = 0, 1
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
+FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill")
 TRACE_STATIC_MAX_RAYS = 4194304
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
@@ -58,7 +59,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("paths", C.c_uint64), ("box_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64), ("trace_launches", C.c_uint64),
-                ("ms_render", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double)]
+                ("ms_render", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
+                ("ms_reduce", C.c_double), ("n_devices", C.c_uint32), ("kernel_form", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -83,6 +85,8 @@ def _load():
     pp = C.POINTER(C.c_void_p)
     sig = {
         "rt_context_create": (i32, [i32, pp]),
+        "rt_context_create_multi": (i32, [i32, C.POINTER(i32), pp]),
+        "rt_context_num_devices": (i32, [vp]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, []),
         "rt_context_stream": (vp, [vp]),
@@ -107,6 +111,9 @@ def _load():
         "rt_trace_device_static": (i32, [vp, vp, sz, f32, f32, vp, vp]),
         "rt_render": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
         "rt_render_device": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
+        "rt_partition": (i32, [u32, u32, C.POINTER(RenderParams)]),
+        "rt_render_multi": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
+        "rt_render_multi_device": (i32, [vp, vp, C.POINTER(RenderParams), vp, C.POINTER(Stats)]),
         "rt_tonemap": (i32, [vp, vp, u32, vp, sz]),
         "rt_tonemap_device": (i32, [vp, vp, u32, vp, sz]),
         # host scene layer (include/rt_host.h)
@@ -141,7 +148,8 @@ def _load():
 
 lib = _load()
 ABI_SYMBOLS = [
-    "rt_context_create", "rt_context_destroy", "rt_last_error", "rt_context_stream",
+    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_destroy", "rt_last_error",
+    "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
     "rt_scene_set_traversal", "rt_scene_commit",
@@ -188,14 +196,24 @@ def _ptr(a):
 
 
 class Context:
-    """One GPU (rt_context)."""
+    """One GPU (rt_context), or with devices=[...] the GPUs of one node behind one context
+    (rt_context_create_multi; devices[0] is the root that single-GPU calls run on)."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, devices=None):
         h = C.c_void_p()
-        _check(lib.rt_context_create(device_id, C.byref(h)))
+        if devices is None:
+            _check(lib.rt_context_create(device_id, C.byref(h)))
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            _check(lib.rt_context_create_multi(len(devices), ids, C.byref(h)))
+            device_id = devices[0]
         self.h = h
         self.device_id = device_id
         _live.add(self)
+
+    @property
+    def num_devices(self):
+        return lib.rt_context_num_devices(self.h)
 
     def close(self):
         if getattr(self, "h", None):
@@ -330,6 +348,23 @@ class Scene:
         _check(lib.rt_render(self.h, _ptr(cam), C.byref(params), _ptr(accum), C.byref(st)))
         return accum, st.as_dict()
 
+    def render_multi(self, camera, params, accum=None):
+        """rt_render_multi: the frame split over every GPU of the (multi-GPU) context and sum-reduced
+        to the root; returns (accum[H,W,3] sums, stats dict)."""
+        cam = np.ascontiguousarray(camera, dtype=camera_dt).reshape(1)
+        if accum is None:
+            accum = np.zeros((params.height, params.width, 3), dtype=np.float32)
+        st = Stats()
+        _check(lib.rt_render_multi(self.h, _ptr(cam), C.byref(params), _ptr(accum), C.byref(st)))
+        return accum, st.as_dict()
+
+    def render_multi_device(self, camera, params, d_accum):
+        """same, adding into a device buffer on the context's root GPU"""
+        cam = np.ascontiguousarray(camera, dtype=camera_dt).reshape(1)
+        st = Stats()
+        _check(lib.rt_render_multi_device(self.h, _ptr(cam), C.byref(params), d_accum, C.byref(st)))
+        return st.as_dict()
+
     def render_device(self, camera, params, d_accum, want_stats=True):
         cam = np.ascontiguousarray(camera, dtype=camera_dt).reshape(1)
         st = Stats()
@@ -451,6 +486,13 @@ class World:
         st = Stats()
         _check(lib.rt_world_render(self.h, width, height, spp, max_bounces, seed, _ptr(acc), C.byref(st)))
         return acc, st.as_dict()
+
+
+def partition_params(params, n_ranks, rank):
+    """rt_partition: a copy of `params` (the whole job) narrowed to the share of `rank` of `n_ranks`."""
+    p = RenderParams.from_buffer_copy(params)
+    _check(lib.rt_partition(n_ranks, rank, C.byref(p)))
+    return p
 
 
 def set_default_build(mode):

@@ -346,6 +346,8 @@ int GpuRenderer::render(uint32_t width, uint32_t height, uint32_t spp, uint32_t 
     p.t_min = 0.001f;                          // main.rs:46
     p.sky_intensity = world_.sky_intensity;
     p.seed = seed;
+    // a context over several GPUs renders the frame on all of them (one reduce to its root)
+    if (rt_context_num_devices(ctx_) > 1) return rt_render_multi(scene_, &c, &p, accum_rgb, stats);
     return rt_render(scene_, &c, &p, accum_rgb, stats);
 }
 
@@ -387,8 +389,10 @@ int GpuRenderer::render_progressive(uint32_t width, uint32_t height, uint32_t sp
     for (uint32_t upto : progressive_schedule(spp)) {
         p.sample_begin = done; p.sample_end = upto;
         rt_stats st;
-        int rc = rt_render(scene_, &c, &p, accum.data(), &st);
+        int rc = rt_context_num_devices(ctx_) > 1 ? rt_render_multi(scene_, &c, &p, accum.data(), &st)
+                                                  : rt_render(scene_, &c, &p, accum.data(), &st);
         if (rc) return rc;
+        total.n_devices = st.n_devices; total.kernel_form = st.kernel_form; total.ms_reduce += st.ms_reduce;
         total.rays_traced += st.rays_traced; total.paths += st.paths;
         total.trace_launches += st.trace_launches; total.ms_render += st.ms_render;
         total.ms_trace += st.ms_trace; total.ms_shade += st.ms_shade;

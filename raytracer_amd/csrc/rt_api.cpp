@@ -3,6 +3,7 @@
 // point that needs one fails with RT_ERR_DEVICE.
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <atomic>
@@ -11,7 +12,9 @@
 #include <cstring>
 #include <memory>
 #include <new>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_internal.hpp"
@@ -102,6 +105,11 @@ struct rt_context {
     // destroyed context is refused.
     std::atomic<int> refs{1};
     bool destroyed = false;
+    // A multi-GPU context is its root (this object, GPU dev_ids[0]) plus one context per further GPU.
+    std::vector<rt_context*> peers;     // GPUs 1 .. n-1 (owned)
+    std::vector<ncclComm_t> comms;      // one communicator per GPU, [0] the root's; empty when the GPUs are not distinct
+    bool multi = false;                 // made by rt_context_create_multi (even with one GPU)
+    DeviceBuffer frame;                 // a peer's full-frame accumulation buffer (rt_render_multi)
 
     LaunchCfg cfg(int pipe = 0) const { return LaunchCfg{(void*)pipes[pipe].stream, grid_cap, wave_target}; }
     ~rt_context() {
@@ -132,6 +140,7 @@ struct rt_scene {
     FlatScene flat;
     DeviceBuffer d_entries, d_units, d_units_oct, d_geo, d_meta, d_mats;
     DevScene dev{};
+    std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
 };
 
 #ifdef RT_STAMPS
@@ -238,9 +247,48 @@ int rt_context_create(int device_id, rt_context** out) {
     RT_GUARD_END("rt_context_create")
 }
 
+int rt_context_create_multi(int n_dev, const int* dev_ids, rt_context** out) {
+    RT_GUARD_BEGIN
+    if (!out) return fail(RT_ERR_INVALID, "rt_context_create_multi: out is NULL");
+    *out = nullptr;
+    if (n_dev < 1 || n_dev > 64 || !dev_ids) return fail(RT_ERR_INVALID, "rt_context_create_multi: needs 1 to 64 device ids");
+    bool distinct = true;
+    for (int i = 0; i < n_dev; i++)
+        for (int j = 0; j < i; j++) distinct = distinct && dev_ids[i] != dev_ids[j];
+    rt_context* root = nullptr;
+    int rc = rt_context_create(dev_ids[0], &root);
+    if (rc) return rc;
+    root->multi = true;
+    for (int i = 1; i < n_dev; i++) {
+        rt_context* peer = nullptr;
+        rc = rt_context_create(dev_ids[i], &peer);
+        if (rc) { rt_context_destroy(root); return rc; }
+        root->peers.push_back(peer);
+    }
+    if (distinct) {                            // one RCCL rank per GPU, all driven by this process
+        root->comms.assign((size_t)n_dev, nullptr);
+        const ncclResult_t nr = ncclCommInitAll(root->comms.data(), n_dev, dev_ids);
+        if (nr != ncclSuccess) {
+            root->comms.clear();
+            rt_context_destroy(root);
+            return fail(RT_ERR_DEVICE, std::string("rt_context_create_multi: ncclCommInitAll: ") + ncclGetErrorString(nr));
+        }
+    }
+    *out = root;
+    return RT_OK;
+    RT_GUARD_END("rt_context_create_multi")
+}
+
+int rt_context_num_devices(const rt_context* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
+
 void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     if (ctx->destroyed) return;
+    for (ncclComm_t c : ctx->comms)
+        if (c) (void)ncclCommDestroy(c);
+    ctx->comms.clear();
+    for (rt_context* peer : ctx->peers) rt_context_destroy(peer);
+    ctx->peers.clear();
     (void)hipSetDevice(ctx->device);
     for (int i = 0; i < ctx->n_pipes; i++)
         if (ctx->pipes[i].stream) (void)hipStreamSynchronize(ctx->pipes[i].stream);
@@ -273,6 +321,8 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
 
 void rt_scene_destroy(rt_scene* scene) {
     if (!scene) return;
+    for (rt_scene* r : scene->replicas) rt_scene_destroy(r);
+    scene->replicas.clear();
     rt_context* ctx = scene->ctx;
     if (ctx) {
         (void)hipSetDevice(ctx->device);
@@ -394,29 +444,24 @@ int rt_scene_set_traversal(rt_scene* s, int mode) {
         if (rc) return rc;
     }
     s->traversal = mode;
+    for (rt_scene* r : s->replicas) {          // the scene's copies on the other GPUs follow
+        int rc = rt_scene_set_traversal(r, mode);
+        if (rc) return rc;
+    }
     return RT_OK;
     RT_GUARD_END("rt_scene_set_traversal")
 }
 
-int rt_scene_commit(rt_scene* s) {
-    RT_GUARD_BEGIN
-    if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
-    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->build_mode, s->flat);
-    if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
+// uploads a flattened scene to the GPU of s->ctx and chooses the kernel form
+static int upload_scene(rt_scene* s, const FlatScene& f) {
     rt_context* ctx = s->ctx;
-    s->dev.n_entries = (uint32_t)s->flat.n_entries();
-    s->dev.n_prims = (uint32_t)s->flat.n_prims();
-    s->ordered_ok = s->flat.ordered_ok;
-    s->dev.n_units = (uint32_t)s->flat.n_units();
-    s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
-    if (!ctx) {                                // host-only scene: keep the flattened arrays
-        s->committed = true;
-        return RT_OK;
-    }
+    s->dev.n_entries = (uint32_t)f.n_entries();
+    s->dev.n_prims = (uint32_t)f.n_prims();
+    s->ordered_ok = f.ordered_ok;
+    s->dev.n_units = (uint32_t)f.n_units();
+    s->dev.stack_depth = std::max<uint32_t>(f.depth, 1u);
     int rc = set_device(ctx);
     if (rc) return rc;
-    const FlatScene& f = s->flat;
     auto upload = [&](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
         if (e != hipSuccess || bytes == 0) return e;
@@ -439,19 +484,48 @@ int rt_scene_commit(rt_scene* s) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     s->dev.entries = s->d_entries.p;
     s->dev.units = s->d_units.p;
-    s->dev.n_units = (uint32_t)f.n_units();
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
     s->dev.materials = s->d_mats.p;
-    s->dev.n_entries = (uint32_t)f.n_entries();
-    s->dev.n_prims = (uint32_t)f.n_prims();
-    s->dev.n_mats = (uint32_t)s->mats.size();
+    s->dev.n_mats = (uint32_t)(f.materials.size() / 8);
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
     s->dev.lds_walk = (s->dev.n_units > 0 && ((size_t)s->dev.n_units + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
-    rc = apply_traversal(s, s->traversal);
+    return apply_traversal(s, s->traversal);
+}
+
+int rt_scene_commit(rt_scene* s) {
+    RT_GUARD_BEGIN
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->build_mode, s->flat);
+    if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
+    rt_context* ctx = s->ctx;
+    s->dev.n_entries = (uint32_t)s->flat.n_entries();
+    s->dev.n_prims = (uint32_t)s->flat.n_prims();
+    s->ordered_ok = s->flat.ordered_ok;
+    s->dev.n_units = (uint32_t)s->flat.n_units();
+    s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
+    if (!ctx) {                                // host-only scene: keep the flattened arrays
+        s->committed = true;
+        return RT_OK;
+    }
+    int rc = upload_scene(s, s->flat);
     if (rc) return rc;
+    // a multi-GPU context: the scene was flattened once; every further GPU gets the same arrays
+    for (rt_context* peer : ctx->peers) {
+        rt_scene* r = new rt_scene();
+        s->replicas.push_back(r);
+        r->ctx = peer;
+        peer->refs.fetch_add(1);
+        r->root_kind = s->root_kind;
+        r->build_mode = s->build_mode;
+        r->traversal = s->traversal;
+        rc = upload_scene(r, s->flat);
+        if (rc) return rc;
+        r->committed = true;
+    }
     // the host copies of the geometry are no longer needed
     for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
     s->flat.entries.clear(); s->flat.entries.shrink_to_fit();
@@ -911,6 +985,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         if (rc) return rc;
         stats->ms_trace = ms_by_kind[0];
         stats->ms_shade = ms_by_kind[1];
+        stats->n_devices = 1;
+        const DevScene& d = s->dev;            // the form the launches above took
+        stats->kernel_form = d.ordered ? RT_FORM_ORDERED
+                             : d.octant ? (d.refill && !staged ? RT_FORM_OCTANT_REFILL : RT_FORM_OCTANT)
+                             : d.sweep ? RT_FORM_SWEEP
+                             : staged ? RT_FORM_WALK
+                             : d.lds_walk ? (d.refill ? RT_FORM_WALK_LDS_REFILL : RT_FORM_WALK_LDS)
+                                          : (d.refill ? RT_FORM_WALK_REFILL : RT_FORM_WALK);
     } else {
         HIP_TRY(hipStreamSynchronize(st0));    // the call returns with the frame complete either way
     }
@@ -938,6 +1020,145 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_render_params* p, floa
     HIP_TRY(hipMemcpy(accum_rgb, d.p, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
     RT_GUARD_END("rt_render")
+}
+
+int rt_partition(uint32_t n_ranks, uint32_t rank, rt_render_params* p) {
+    if (!p) return fail(RT_ERR_INVALID, "rt_partition: NULL params");
+    if (n_ranks < 1 || rank >= n_ranks) return fail(RT_ERR_INVALID, "rt_partition: rank out of range");
+    if (p->band_count > 1) return fail(RT_ERR_INVALID, "rt_partition: params already describe a band group");
+    if (p->sample_begin > p->sample_end) return fail(RT_ERR_INVALID, "rt_partition: bad sample range");
+    const uint32_t spp = p->sample_end - p->sample_begin;
+    uint32_t groups = (n_ranks >= 4 && n_ranks % 2 == 0) ? 2u : 1u;
+    uint32_t parts = n_ranks / groups;
+    if (parts > spp) { groups = n_ranks; parts = 1; }      // fewer samples than parts: split by bands only
+    const uint32_t group = rank % groups, part = rank / groups;
+    const uint32_t base = spp / parts, extra = spp % parts;
+    const uint32_t begin = part * base + std::min(part, extra);
+    const uint32_t count = base + (part < extra ? 1u : 0u);
+    p->sample_begin += begin;
+    p->sample_end = p->sample_begin + count;
+    p->band_rows = 64;                         // BLOCK_SIZE, main.rs:22
+    p->band_count = groups;
+    p->band_index = group;
+    return RT_OK;
+}
+
+int rt_render_multi_device(rt_scene* s, const rt_camera* cam, const rt_render_params* p, void* d_accum,
+                           rt_stats* stats) {
+    RT_GUARD_BEGIN
+    if (!s || !cam || !p || !d_accum) return fail(RT_ERR_INVALID, "rt_render_multi: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    rt_context* root = s->ctx;
+    if (root->destroyed) return fail(RT_ERR_STATE, "the context of this scene has been destroyed");
+    if (!root->multi) return fail(RT_ERR_STATE, "rt_render_multi needs a context made by rt_context_create_multi");
+    if (p->band_count > 1) return fail(RT_ERR_INVALID, "rt_render_multi splits the frame itself: band_count must be unset");
+    const int n = 1 + (int)root->peers.size();
+    if ((int)s->replicas.size() != n - 1) return fail(RT_ERR_STATE, "rt_render_multi: the scene was not committed on this context");
+    const size_t n_floats = (size_t)p->width * p->height * 3;
+
+    // every GPU renders its share on a host thread of its own
+    struct Worker { int rc = RT_OK; std::string err; rt_stats st; };
+    std::vector<Worker> work((size_t)n);
+    auto job = [&](int r) {
+        Worker& w = work[(size_t)r];
+        std::memset(&w.st, 0, sizeof(w.st));
+        rt_scene* sc = r == 0 ? s : s->replicas[(size_t)r - 1];
+        rt_context* ctx = sc->ctx;
+        rt_render_params pr = *p;
+        w.rc = rt_partition((uint32_t)n, (uint32_t)r, &pr);
+        void* buf = d_accum;
+        if (w.rc == RT_OK && r > 0) {          // a peer accumulates into its own zeroed frame
+            hipError_t e = hipSetDevice(ctx->device);
+            if (e == hipSuccess) e = ctx->frame.ensure(n_floats * sizeof(float));
+            if (e == hipSuccess) e = hipMemsetAsync(ctx->frame.p, 0, n_floats * sizeof(float), ctx->stream);
+            if (e != hipSuccess) w.rc = fail(RT_ERR_DEVICE, std::string("rt_render_multi: frame buffer: ") + hipGetErrorString(e));
+            buf = ctx->frame.p;
+        }
+        if (w.rc == RT_OK && pr.sample_begin < pr.sample_end) w.rc = rt_render_device(sc, cam, &pr, buf, &w.st);
+        else if (w.rc == RT_OK && r > 0) w.rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? RT_OK : fail(RT_ERR_DEVICE, "rt_render_multi: synchronize");
+        if (w.rc != RT_OK) w.err = g_last_error;   // the message lives in this thread
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int r = 1; r < n; r++) threads.emplace_back(job, r);
+        job(0);
+        for (std::thread& t : threads) t.join();
+    }
+    for (const Worker& w : work)
+        if (w.rc != RT_OK) return fail(w.rc, w.err);
+
+    // the one collective: sum the frames to the root (every render above has drained its stream)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n > 1 && !root->comms.empty()) {
+        ncclResult_t nr = ncclGroupStart();
+        for (int r = 0; r < n && nr == ncclSuccess; r++) {
+            rt_context* ctx = r == 0 ? root : root->peers[(size_t)r - 1];
+            const void* send = r == 0 ? d_accum : ctx->frame.p;
+            nr = ncclReduce(send, d_accum, n_floats, ncclFloat, ncclSum, 0, root->comms[(size_t)r], ctx->stream);
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("rt_render_multi: ncclReduce: ") + ncclGetErrorString(nr));
+        for (int r = 0; r < n; r++) {
+            rt_context* ctx = r == 0 ? root : root->peers[(size_t)r - 1];
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    } else if (n == 1 && !root->comms.empty()) {
+        // one GPU: the same call, a reduce over one rank (in place)
+        const ncclResult_t nr = ncclReduce(d_accum, d_accum, n_floats, ncclFloat, ncclSum, 0, root->comms[0], root->stream);
+        if (nr != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("rt_render_multi: ncclReduce: ") + ncclGetErrorString(nr));
+        HIP_TRY(hipSetDevice(root->device));
+        HIP_TRY(hipStreamSynchronize(root->stream));
+    } else if (n > 1) {
+        // the workers share one GPU: add their frames in rank order
+        HIP_TRY(hipSetDevice(root->device));
+        for (int r = 1; r < n; r++)
+            if (launch_add_frame(root->cfg(), d_accum, root->peers[(size_t)r - 1]->frame.p, n_floats))
+                return fail(RT_ERR_DEVICE, "rt_render_multi: add launch failed");
+        HIP_TRY(hipStreamSynchronize(root->stream));
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    const double ms_reduce = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) {
+        *stats = work[0].st;
+        for (int r = 1; r < n; r++) {
+            const rt_stats& o = work[(size_t)r].st;
+            stats->rays_traced += o.rays_traced; stats->paths += o.paths;
+            stats->box_tests += o.box_tests; stats->tri_tests += o.tri_tests; stats->sph_tests += o.sph_tests;
+            stats->trace_launches += o.trace_launches;
+            stats->ms_render = std::max(stats->ms_render, o.ms_render);
+            stats->ms_trace = std::max(stats->ms_trace, o.ms_trace);
+            stats->ms_shade = std::max(stats->ms_shade, o.ms_shade);
+        }
+        stats->ms_reduce = ms_reduce;
+        stats->n_devices = (uint32_t)n;
+    }
+    return RT_OK;
+    RT_GUARD_END("rt_render_multi")
+}
+
+int rt_render_multi(rt_scene* s, const rt_camera* cam, const rt_render_params* p, float* accum_rgb, rt_stats* stats) {
+    RT_GUARD_BEGIN
+    if (!s || !p || !accum_rgb) return fail(RT_ERR_INVALID, "rt_render_multi: NULL argument");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "host-only scene: no GPU context");
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    const size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    DeviceBuffer& d = ctx->frame_in;
+    HIP_TRY(d.ensure(bytes));
+    HIP_TRY(hipMemcpy(d.p, accum_rgb, bytes, hipMemcpyHostToDevice));
+    rt_stats local;
+    rt_stats* st = stats ? stats : &local;
+    rc = rt_render_multi_device(s, cam, p, d.p, st);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpy(accum_rgb, d.p, bytes, hipMemcpyDeviceToHost));
+    st->ms_reduce += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return RT_OK;
+    RT_GUARD_END("rt_render_multi")
 }
 
 int rt_tonemap_device(rt_context* ctx, const void* d_accum, uint32_t spp, void* d_out, size_t npix) {

@@ -1503,6 +1503,20 @@ int launch_accumulate(const LaunchCfg& cfg, const BatchGeom& g, const RenderBuff
     return check_launch();
 }
 
+// dst[i] += src[i]: sums the per-worker frames when several workers share one GPU (where RCCL,
+// which refuses two ranks on a device, cannot be used) and adds a reduced frame to the caller's
+__global__ void __launch_bounds__(RT_BLOCK)
+k_add_frame(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * RT_BLOCK)
+        dst[i] += src[i];
+}
+int launch_add_frame(const LaunchCfg& cfg, void* d_dst, const void* d_src, size_t n) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_add_frame, dim3(grid_for(n, cfg.grid_cap)), dim3(RT_BLOCK), 0, (hipStream_t)cfg.stream,
+                       (float*)d_dst, (const float*)d_src, n);
+    return check_launch();
+}
+
 int launch_tonemap(const LaunchCfg& cfg, const void* d_accum, uint32_t spp, void* d_out, size_t npix) {
     if (npix == 0) return 0;
     hipStream_t st = (hipStream_t)cfg.stream;

@@ -194,5 +194,6 @@ int launch_path(const LaunchCfg&, const DevScene&, const rt_camera&, const Batch
 int launch_accumulate(const LaunchCfg&, const BatchGeom&, const RenderBuffers&, void* d_accum,
                       uint32_t max_bounces);
 int launch_tonemap(const LaunchCfg&, const void* d_accum, uint32_t spp, void* d_out, size_t npix);
+int launch_add_frame(const LaunchCfg&, void* d_dst, const void* d_src, size_t n_floats);   // dst += src
 
 }  // namespace rtamd

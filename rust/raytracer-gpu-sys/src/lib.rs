@@ -1,7 +1,7 @@
 //! UNVERIFIED: written without a Rust toolchain; the layouts below restate include/rt_abi.h and
 //! include/rt_host.h field by field (tests/test_host_layer.py checks the same sizes from Python:
 //! rt_material 24, rt_sphere 20, rt_triangle 52, rt_ray 24, rt_hit 40, rt_camera 76,
-//! rt_render_params 80, rt_stats 72 bytes).
+//! rt_render_params 80, rt_stats 88 bytes).
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -25,6 +25,14 @@ pub const RT_RENDER_PROFILE: u32 = 1;
 pub const RT_RENDER_COUNT_VISITS: u32 = 2;
 pub const RT_RENDER_STAGED: u32 = 4;
 pub const RT_MISS: u32 = 0xFFFF_FFFF;
+pub const RT_FORM_SWEEP: u32 = 0;
+pub const RT_FORM_WALK: u32 = 1;
+pub const RT_FORM_WALK_LDS: u32 = 2;
+pub const RT_FORM_WALK_REFILL: u32 = 3;
+pub const RT_FORM_WALK_LDS_REFILL: u32 = 4;
+pub const RT_FORM_ORDERED: u32 = 5;
+pub const RT_FORM_OCTANT: u32 = 6;
+pub const RT_FORM_OCTANT_REFILL: u32 = 7;
 pub const RT_TRACE_STATIC_MAX_RAYS: u32 = 4194304;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
@@ -53,6 +61,7 @@ pub struct rt_render_params {
 pub struct rt_stats {
     pub rays_traced: u64, pub paths: u64, pub box_tests: u64, pub tri_tests: u64, pub sph_tests: u64,
     pub trace_launches: u64, pub ms_render: f64, pub ms_trace: f64, pub ms_shade: f64,
+    pub ms_reduce: f64, pub n_devices: u32, pub kernel_form: u32,
 }
 pub enum rt_context {}
 pub enum rt_scene {}
@@ -64,6 +73,8 @@ pub type rt_block_fn = Option<unsafe extern "C" fn(user: *mut c_void, x: u32, y:
 
 extern "C" {
     pub fn rt_context_create(device_id: c_int, out: *mut *mut rt_context) -> c_int;
+    pub fn rt_context_create_multi(n_dev: c_int, dev_ids: *const c_int, out: *mut *mut rt_context) -> c_int;
+    pub fn rt_context_num_devices(ctx: *const rt_context) -> c_int;
     pub fn rt_context_destroy(ctx: *mut rt_context);
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_context_stream(ctx: *mut rt_context) -> *mut c_void;
@@ -94,6 +105,11 @@ extern "C" {
                      accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;
     pub fn rt_render_device(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
                             d_accum_rgb: *mut c_void, stats: *mut rt_stats) -> c_int;
+    pub fn rt_partition(n_ranks: u32, rank: u32, params: *mut rt_render_params) -> c_int;
+    pub fn rt_render_multi(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
+                           accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;
+    pub fn rt_render_multi_device(scene: *mut rt_scene, cam: *const rt_camera, params: *const rt_render_params,
+                                  d_accum_rgb: *mut c_void, stats: *mut rt_stats) -> c_int;
     pub fn rt_tonemap(ctx: *mut rt_context, accum_rgb: *const f32, spp: u32, out_0rgb: *mut u32, npix: usize) -> c_int;
     pub fn rt_tonemap_device(ctx: *mut rt_context, d_accum_rgb: *const c_void, spp: u32, d_out_0rgb: *mut c_void,
                              npix: usize) -> c_int;

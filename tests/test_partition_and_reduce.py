@@ -26,6 +26,27 @@ def test_partition_covers_every_pixel_sample_once(world, shape):
     assert (cover == spp).all()
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8, 16])
+def test_library_partition_is_the_python_one(world):
+    """rt_partition (what rt_render_multi gives every GPU, and what a one-process-per-GPU job asks
+    for) against partition.py, including a job that starts at a later sample and one with fewer
+    samples than ranks."""
+    import raytracer_amd as rt
+    for w, h, s0, s1 in [(1024, 1024, 0, 1024), (100, 77, 5, 17), (64, 200, 0, 3), (1920, 1080, 100, 356)]:
+        job = rt.Scene.params(w, h, s1, 6, 0.5, samples=(s0, s1))
+        for r in range(world):
+            (rows, groups, group), (a, b) = P.partition(w, h, s1 - s0, world, r)
+            p = rt.partition_params(job, world, r)
+            assert (p.band_rows, p.band_count, p.band_index) == (rows, groups, group)
+            assert (p.sample_begin, p.sample_end) == (s0 + a, s0 + b)
+            assert (p.width, p.height, p.x0, p.y0, p.x1, p.y1, p.seed) == (w, h, 0, 0, w, h, job.seed)
+        assert (job.band_count, job.sample_begin, job.sample_end) == (0, s0, s1)      # the job itself is untouched
+    with pytest.raises(rt.RtError):
+        rt.partition_params(rt.Scene.params(8, 8, 4, 6, 0.5), 2, 2)
+    with pytest.raises(rt.RtError):
+        rt.partition_params(rt.Scene.params(64, 64, 4, 6, 0.5, bands=(16, 2, 0)), 2, 0)
+
+
 def test_split_factors():
     assert P.split_factors(1, 1024) == (1, 1)
     assert P.split_factors(2, 1024) == (1, 2)
