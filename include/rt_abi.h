@@ -206,6 +206,16 @@ int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
  * sphere 32-byte aligned); skip links count units */
 size_t rt_scene_num_units(const rt_scene* scene);
 int rt_scene_get_units(const rt_scene* scene, float* out, size_t n_floats);
+/* host-only scenes: the units as the reference-order per-lane walks read them.  The same entries
+ * (a box or sphere in two 16-byte units, a triangle in three), but every entry names its
+ * successors itself -- a box: word 3 = tag | skip (where the walk goes when the box is missed),
+ * word 7 = its first child; a triangle: word 11, a sphere: word 5 = the entry behind it; all
+ * unit indices, the index one past the last unit meaning "done" -- so the order in memory is free
+ * and is chosen for locality (the children of a box side by side, a pair of boxes inside one
+ * 64-byte line, the top levels of the trees first).  Entry 0 of rt_scene_get_entries() is at unit
+ * 0; following the links from there visits the entries in the reference's order. */
+size_t rt_scene_num_walk_units(const rt_scene* scene);
+int rt_scene_get_walk_units(const rt_scene* scene, float* out, size_t n_floats);
 
 /* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */
 int rt_trace(rt_scene* scene, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out);

@@ -106,6 +106,8 @@ def _load():
         "rt_scene_get_entries": (i32, [vp, vp, sz]),
         "rt_scene_num_units": (sz, [vp]),
         "rt_scene_get_units": (i32, [vp, vp, sz]),
+        "rt_scene_num_walk_units": (sz, [vp]),
+        "rt_scene_get_walk_units": (i32, [vp, vp, sz]),
         "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
         "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
         "rt_trace_device_static": (i32, [vp, vp, sz, f32, f32, vp, vp]),
@@ -154,7 +156,7 @@ ABI_SYMBOLS = [
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
     "rt_scene_set_traversal", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
-    "rt_scene_get_units", "rt_trace",
+    "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_trace",
     "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
 HOST_SYMBOLS = [
@@ -311,6 +313,12 @@ class Scene:
         """The entries as the per-lane walks read them: (n_units, 4) floats, 16-byte units."""
         out = np.zeros((lib.rt_scene_num_units(self.h), 4), dtype=np.float32)
         _check(lib.rt_scene_get_units(self.h, _ptr(out), out.size))
+        return out
+
+    def walk_units(self):
+        """The units in the linked, locality-ordered form of the reference-order per-lane walks."""
+        out = np.zeros((lib.rt_scene_num_walk_units(self.h), 4), dtype=np.float32)
+        _check(lib.rt_scene_get_walk_units(self.h, _ptr(out), out.size))
         return out
 
     def trace(self, rays, t_min=0.001, t_max=np.inf):

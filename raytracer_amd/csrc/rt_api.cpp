@@ -138,7 +138,7 @@ struct rt_scene {
     uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
     bool committed = false;
     FlatScene flat;
-    DeviceBuffer d_entries, d_units, d_units_oct, d_geo, d_meta, d_mats;
+    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats;
     DevScene dev{};
     std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
 };
@@ -459,6 +459,8 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     s->dev.n_prims = (uint32_t)f.n_prims();
     s->ordered_ok = f.ordered_ok;
     s->dev.n_units = (uint32_t)f.n_units();
+    s->dev.n_walk = (uint32_t)f.n_walk();
+    s->dev.walk_top_units = f.walk_top_units;
     s->dev.stack_depth = std::max<uint32_t>(f.depth, 1u);
     int rc = set_device(ctx);
     if (rc) return rc;
@@ -478,19 +480,21 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     }
     HIP_TRY(upload(s->d_entries, f.entries.data(), f.entries.size() * 4));
     HIP_TRY(upload(s->d_units, f.units.data(), f.units.size() * 4));
+    HIP_TRY(upload(s->d_walk, f.walk.data(), f.walk.size() * 4));
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
     HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     s->dev.entries = s->d_entries.p;
     s->dev.units = s->d_units.p;
+    s->dev.walk = s->d_walk.p;
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
     s->dev.materials = s->d_mats.p;
     s->dev.n_mats = (uint32_t)(f.materials.size() / 8);
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
-    s->dev.lds_walk = (s->dev.n_units > 0 && ((size_t)s->dev.n_units + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
+    s->dev.lds_walk = (s->dev.n_walk > 0 && ((size_t)s->dev.n_walk + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
                        !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     return apply_traversal(s, s->traversal);
 }
@@ -506,6 +510,8 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_prims = (uint32_t)s->flat.n_prims();
     s->ordered_ok = s->flat.ordered_ok;
     s->dev.n_units = (uint32_t)s->flat.n_units();
+    s->dev.n_walk = (uint32_t)s->flat.n_walk();
+    s->dev.walk_top_units = s->flat.walk_top_units;
     s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
     if (!ctx) {                                // host-only scene: keep the flattened arrays
         s->committed = true;
@@ -530,6 +536,7 @@ int rt_scene_commit(rt_scene* s) {
     for (SceneObject& o : s->objects) { o.tris.clear(); o.tris.shrink_to_fit(); }
     s->flat.entries.clear(); s->flat.entries.shrink_to_fit();
     s->flat.units.clear(); s->flat.units.shrink_to_fit();
+    s->flat.walk.clear(); s->flat.walk.shrink_to_fit();
     s->flat.prim_geo.clear(); s->flat.prim_geo.shrink_to_fit();
     s->committed = true;
     return RT_OK;
@@ -554,6 +561,16 @@ int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_units needs a committed host-only scene");
     if (n_floats != s->flat.n_units() * 4) return fail(RT_ERR_INVALID, "rt_scene_get_units: size mismatch");
     std::memcpy(out, s->flat.units.data(), n_floats * sizeof(float));   // (without the end units)
+    return RT_OK;
+}
+
+size_t rt_scene_num_walk_units(const rt_scene* s) { return s ? s->dev.n_walk : 0; }
+
+int rt_scene_get_walk_units(const rt_scene* s, float* out, size_t n_floats) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "rt_scene_get_walk_units: NULL argument");
+    if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_walk_units needs a committed host-only scene");
+    if (n_floats != s->flat.n_walk() * 4) return fail(RT_ERR_INVALID, "rt_scene_get_walk_units: size mismatch");
+    std::memcpy(out, s->flat.walk.data(), n_floats * sizeof(float));   // (without the end units)
     return RT_OK;
 }
 

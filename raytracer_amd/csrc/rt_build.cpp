@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -375,7 +376,7 @@ bool pack_units(FlatScene& out) {       // false: the unit links do not fit 30 b
     out.units.assign((size_t)(u + UNITS_END) * 4, 0.0f);
     {
         const uint32_t end_word = TAG_END << TAG_SHIFT;     // the end units: only the tag word matters
-        std::memcpy(&out.units[(size_t)u * 4 + 3], &end_word, 4);
+        for (uint32_t k = 0; k < UNITS_END; k++) std::memcpy(&out.units[((size_t)u + k) * 4 + 3], &end_word, 4);
     }
     for (size_t i = 0; i < n; i++) {
         const float* e = &out.entries[i * ENTRY_FLOATS];
@@ -391,6 +392,90 @@ bool pack_units(FlatScene& out) {       // false: the unit links do not fit 30 b
         } else if (tag == TAG_TRI) {
             const uint32_t stride = unit_of[i + 1] - unit_of[i];      // 3, or 4 with a padding unit
             std::memcpy(&d[11], &stride, 4);
+        }
+    }
+    return true;
+}
+
+// Word offsets of the explicit links inside an entry's units (FlatScene::walk, octant copies).
+constexpr int LINK_BOX_CHILD = 7, LINK_TRI_NEXT = 11, LINK_SPH_NEXT = 5;
+
+// FlatScene::walk: see rt_internal.hpp.  A "group" is the run of siblings under one box (or the
+// top-level entries); groups are laid out breadth first until `top_budget` units are used, the
+// rest depth first (a group, then the groups below its members in order).  The successor of an
+// entry in the reference's visiting order is the entry behind its subtree in pre-order, whatever
+// the memory order, so with pos[] = unit of every entry the links are pos[skip], pos[i + 1].
+bool pack_walk_units(FlatScene& out, uint32_t top_budget, uint32_t pair_align) {
+    const size_t n = out.n_entries();
+    auto word = [&](size_t i, int k) { uint32_t u; std::memcpy(&u, &out.entries[i * ENTRY_FLOATS + k], 4); return u; };
+    auto tag_of = [&](size_t i) { return word(i, 3) >> TAG_SHIFT; };
+    auto end_of = [&](size_t i) { return tag_of(i) == TAG_BOX ? (size_t)(word(i, 3) & SKIP_MASK) : i + 1; };
+    std::vector<uint32_t> pos(n + 1);
+    uint64_t u = 0;
+    struct Group { size_t first, end; };
+    auto place = [&](const Group& g) {         // the siblings side by side
+        bool only_pairs = true;
+        size_t members = 0;
+        for (size_t c = g.first; c < g.end; c = end_of(c), members++) only_pairs = only_pairs && tag_of(c) != TAG_TRI;
+        if (only_pairs && members >= 2 && pair_align > 1) u = (u + pair_align - 1) / pair_align * pair_align;
+        for (size_t c = g.first; c < g.end; c = end_of(c)) {
+            if (tag_of(c) != TAG_TRI && (u & 1u)) u++;     // boxes and spheres: 32-byte aligned
+            pos[c] = (uint32_t)u;
+            u += tag_of(c) == TAG_TRI ? 3 : 2;
+            if (u > SKIP_MASK) return;
+        }
+    };
+    std::vector<Group> queue{Group{0, n}};
+    size_t head = 0;
+    if (std::getenv("RT_LAYOUT_PREORDER")) {   // experiments: the entries in pre-order (a box, then its first child)
+        for (size_t i = 0; i < n; i++) {
+            if (tag_of(i) != TAG_TRI && (u & 1u)) u++;
+            pos[i] = (uint32_t)u;
+            u += tag_of(i) == TAG_TRI ? 3 : 2;
+            if (u > SKIP_MASK) return false;
+        }
+        queue.clear();
+    }
+    while (head < queue.size() && u < top_budget) {        // breadth first: the top of the trees
+        const Group g = queue[head++];
+        place(g);
+        for (size_t c = g.first; c < g.end; c = end_of(c))
+            if (tag_of(c) == TAG_BOX && c + 1 < end_of(c)) queue.push_back(Group{c + 1, end_of(c)});
+    }
+    out.walk_top_units = (uint32_t)std::min<uint64_t>(u, top_budget ? UINT32_MAX : 0);
+    std::vector<Group> stack;                  // depth first for the rest, in breadth-first order of their roots
+    for (size_t q = queue.size(); q > head; q--) stack.push_back(queue[q - 1]);
+    std::vector<Group> below;
+    while (!stack.empty()) {
+        const Group g = stack.back();
+        stack.pop_back();
+        place(g);
+        if (u > SKIP_MASK) return false;
+        below.clear();
+        for (size_t c = g.first; c < g.end; c = end_of(c))
+            if (tag_of(c) == TAG_BOX && c + 1 < end_of(c)) below.push_back(Group{c + 1, end_of(c)});
+        for (size_t k = below.size(); k > 0; k--) stack.push_back(below[k - 1]);   // first member's group next
+    }
+    if (u & 1u) u++;
+    if (u + UNITS_END > SKIP_MASK) return false;
+    pos[n] = (uint32_t)u;                      // where the last entries' links lead: the end units
+    out.walk.assign((size_t)(u + UNITS_END) * 4, 0.0f);
+    const uint32_t end_word = TAG_END << TAG_SHIFT;
+    for (uint32_t k = 0; k < UNITS_END; k++) std::memcpy(&out.walk[((size_t)u + k) * 4 + 3], &end_word, 4);
+    for (size_t i = 0; i < n; i++) {
+        const float* e = &out.entries[i * ENTRY_FLOATS];
+        float* d = &out.walk[(size_t)pos[i] * 4];
+        const uint32_t tag = tag_of(i);
+        std::memcpy(d, e, tag == TAG_TRI ? 48 : 32);
+        const uint32_t next = pos[end_of(i)];
+        if (tag == TAG_BOX) {
+            const uint32_t skip = (TAG_BOX << TAG_SHIFT) | next, child = pos[i + 1];   // (a childless box: child == skip)
+            std::memcpy(&d[3], &skip, 4);
+            std::memcpy(&d[LINK_BOX_CHILD], &child, 4);
+        } else if (tag == TAG_TRI) {
+            std::memcpy(&d[LINK_TRI_NEXT], &next, 4);
+        } else {
+            std::memcpy(&d[LINK_SPH_NEXT], &next, 4);
         }
     }
     return true;
@@ -447,7 +532,16 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
             OctantCopy c{units, out.data() + (size_t)oct * stride * 4, (uint32_t)(oct * stride), oct};
             uint32_t pos = 0;
             for (uint32_t u = 0; u < n_units; u = c.end_of(u)) pos = c.emit(u, pos);   // top-level entries in order
-            c.dst[(size_t)pos * 4 + 3] = TAG_END << TAG_SHIFT;                          // this copy's end units
+            for (uint32_t k = 0; k < UNITS_END; k++)                                    // this copy's end units
+                c.dst[((size_t)pos + k) * 4 + 3] = TAG_END << TAG_SHIFT;
+            // the walk reads its successors from the entries: child / next links of this pre-order
+            for (uint32_t u = 0; u < pos;) {
+                uint32_t* d = c.dst + (size_t)u * 4;
+                const uint32_t t = d[3] >> TAG_SHIFT;
+                if (t == TAG_BOX) { d[LINK_BOX_CHILD] = c.base + u + 2; u += 2; }
+                else if (t == TAG_TRI) { const uint32_t stride = d[LINK_TRI_NEXT]; d[LINK_TRI_NEXT] = c.base + u + stride; u += stride; }
+                else { d[LINK_SPH_NEXT] = c.base + u + 2; u += 2; }
+            }
         });
     for (std::thread& w : workers) w.join();
 }
@@ -523,6 +617,10 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
     annotate_children(out);
     if (!pack_units(out)) return "scene too large for 30-bit unit links";
+    uint32_t top_budget = 2048, pair_align = 4;            // experiments: RT_LAYOUT_TOP / RT_LAYOUT_ALIGN (units)
+    if (const char* e = std::getenv("RT_LAYOUT_TOP")) top_budget = (uint32_t)std::max(0l, std::atol(e));
+    if (const char* e = std::getenv("RT_LAYOUT_ALIGN")) pair_align = (uint32_t)std::max(1l, std::atol(e));
+    if (!pack_walk_units(out, top_budget, pair_align)) return "scene too large for 30-bit unit links";
     return std::string();
 }
 

@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, c
     const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
     const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
     const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
-    return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : r.i + 2;             // a box takes two units: its first child follows it
+    return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : f2u(b.w);            // missed: the skip link; hit: the first child
 }
 
 // shape.rs:411-450 on the triangle (a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2, b.w = prim id)
@@ -160,12 +160,13 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
 #define RT_UTIL_TRIP(cnt)
 #endif
 // Per-lane walk of a whole wave (call converged; lanes without a ray pass valid = false).  Every
-// lane visits its own entries in the reference's order.  `ent` is the compact form of the entry
-// array: 16-byte units (one float4 each), a box or a sphere in two units, a triangle in three (the
-// third holds its v0v2 and, in its last word, the distance to the next entry: 3, or 4 where a
-// padding unit keeps the box or sphere behind it 32-byte aligned); cursors and skip links count units, so a cursor is the index of the
-// entry's first float4.  A box visit therefore touches 32 bytes, and a box and its first child
-// are neighbours in memory.  A lane that stands at a primitive waits
+// lane visits its own entries in the reference's order.  `ent` is the linked form of the entry
+// array: 16-byte units (one float4 each), a box or a sphere in two units, a triangle in three;
+// cursors and links count units, so a cursor is the index of the entry's first float4, and every
+// entry names its successors itself: a box its skip link (a.w) and its first child (b.w), a
+// triangle (c.w) and a sphere (b.y) the entry behind them.  Memory order is therefore the host's
+// choice (the children of a box side by side in one 64-byte fetch, the top levels first).  A box
+// visit touches 32 bytes.  A lane that stands at a primitive waits
 // there while boxes remain to be tested by other lanes, until prim_wait lanes stand at
 // primitives (or no lane stands at a box): the long primitive routines then run with many lanes
 // instead of once per loop trip for a few.
@@ -176,6 +177,79 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
 __device__ __forceinline__ uint32_t octant_of(float dx, float dy, float dz) {
     return (dx >= 0.0f ? 0u : 1u) | (dy >= 0.0f ? 0u : 2u) | (dz >= 0.0f ? 0u : 4u);
 }
+// The units at a lane's cursor.  RT_WALK_LOADS of them are fetched whenever the cursor moves: two
+// hold a box or a sphere, the third completes a triangle (otherwise it is fetched when the triangle
+// is tested, a second round trip to memory), and with four the trip below can test the box BEHIND
+// the one at the cursor as well.
+#ifndef RT_WALK_LOADS
+#define RT_WALK_LOADS 2
+#endif
+// 1: a trip that finds "the next entry to visit is the box right behind this one" (a missed box
+// whose sibling lies beside it; in a pre-order layout a hit box and its first child) tests that box
+// in the same trip.  No primitive lies between the two tests, so the second sees the best_t the
+// reference's recursion would hand it; the visits and their order do not change, a lane just
+// makes fewer trips (and every trip of a walk from memory is a round trip to L2 or HBM).
+#ifndef RT_WALK_PAIR
+#define RT_WALK_PAIR 0
+#endif
+#ifndef RT_WALK_MERGE
+#define RT_WALK_MERGE 0
+#endif
+static_assert(RT_WALK_PAIR == 0 || RT_WALK_LOADS == 4, "the second box of a trip is the third and fourth unit");
+struct LaneEntry { float4 a, b, c, d; };
+__device__ __forceinline__ void fetch_entry(const float4* __restrict__ ent, uint32_t i, LaneEntry& e) {
+    e.a = ent[i]; e.b = ent[i + 1];            // (behind the last entry: the TAG_END units)
+    if (RT_WALK_LOADS >= 3) e.c = ent[i + 2];
+    if (RT_WALK_LOADS >= 4) e.d = ent[i + 3];
+}
+// One trip of the per-lane walk for the whole wave: lanes at a box test it and move on; lanes at a
+// primitive run its routine once enough of them wait (or no lane stands at a box).  Returns false
+// when no lane has an entry left.  A lane without a further entry holds TAG_END in the tag word of
+// e.a, so "at a box" and "at a primitive" are single compares whose lane masks are the ballots.
+template <bool COUNT>
+__device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32_t prim_wait, LaneRay& r, LaneEntry& e,
+                                          float t_min, Counts& cnt) {
+    const uint32_t tag = f2u(e.a.w) >> TAG_SHIFT;
+    const bool at_box = tag == TAG_BOX;
+    const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
+    static_assert(TAG_TRI == 1 && TAG_SPH == 2 && TAG_END == 3, "tag order");
+    const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
+    if ((mb | mp) == 0ull) return false;
+    RT_UTIL_TRIP(cnt);
+    if (at_box) {
+        if (COUNT) cnt.box++;
+        uint32_t nxt = box_step(e.a, e.b, r, t_min);
+        if (RT_WALK_PAIR) {
+            const bool chain = nxt == r.i + 2u && (f2u(e.c.w) >> TAG_SHIFT) == TAG_BOX;
+            const uint32_t nxt2 = box_step(e.c, e.d, r, t_min);
+            if (COUNT) cnt.box += chain ? 1u : 0u;
+            nxt = chain ? nxt2 : nxt;
+        }
+        r.i = nxt;
+        if (!RT_WALK_MERGE) fetch_entry(ent, r.i, e);
+    }
+    const bool run_prims = mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait;      // wave-uniform
+    if (run_prims) {
+        if (at_prim) {
+            if (tag == TAG_TRI) {
+                if (COUNT) cnt.tri++;
+                const float4 c = RT_WALK_LOADS >= 3 ? e.c : ent[r.i + 2];
+                tri_step(e.a, e.b, c, r, t_min);
+                r.i = f2u(c.w);                // the entry behind the triangle
+            } else {
+                if (COUNT) cnt.sph++;
+                sphere_step(e.a, e.b, r, t_min);
+                r.i = f2u(e.b.y);              // the entry behind the sphere
+            }
+            if (!RT_WALK_MERGE) fetch_entry(ent, r.i, e);
+        }
+    }
+    // one fetch for every lane whose cursor moved in this trip (the address unit is busy for the
+    // same 16-20 cycles per load instruction however few lanes take part)
+    if (RT_WALK_MERGE && (at_box || (run_prims && at_prim))) fetch_entry(ent, r.i, e);
+    return true;
+}
+
 template <bool COUNT, bool OCT = false>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                             bool valid, float ox,
@@ -184,43 +258,13 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(dx, dy, dz);   // the lane's copy
-    // The unit array ends with two TAG_END units (every copy of it does, in the octant form), which
-    // is where the last entries' links lead: a lane fetches its next entry unconditionally, and a
-    // lane that has walked off the end -- or never had a ray -- holds TAG_END in the tag word of `a`.
-    // Whether a lane stands at a box or at a primitive is one compare of that word, whose lane mask
-    // is the ballot.
+    // The unit array ends with TAG_END units (every copy of it does, in the octant form), which is
+    // where the last entries' links lead: a lane fetches its next entry unconditionally, and a
+    // lane that has walked off the end -- or never had a ray -- holds TAG_END in the tag word of e.a.
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
-    float4 a = ended, b = ended;
-    if (valid) { a = ent[r.i]; b = ent[r.i + 1]; }
-    for (;;) {
-        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
-        const bool at_box = tag == TAG_BOX;
-        const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
-        static_assert(TAG_TRI == 1 && TAG_SPH == 2 && TAG_END == 3, "tag order");
-        const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
-        if ((mb | mp) == 0ull) break;
-        RT_UTIL_TRIP(cnt);
-        if (at_box) {
-            if (COUNT) cnt.box++;
-            r.i = box_step(a, b, r, t_min);
-            a = ent[r.i]; b = ent[r.i + 1];    // (behind the last entry: the TAG_END units)
-        }
-        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
-            if (at_prim) {
-                if (tag == TAG_TRI) {
-                    if (COUNT) cnt.tri++;
-                    const float4 c = ent[r.i + 2];
-                    tri_step(a, b, c, r, t_min);
-                    r.i = r.i + f2u(c.w);      // a triangle takes three units, or four with padding behind it
-                } else {
-                    if (COUNT) cnt.sph++;
-                    sphere_step(a, b, r, t_min);
-                    r.i = r.i + 2;
-                }
-                a = ent[r.i]; b = ent[r.i + 1];
-            }
-        }
-    }
+    LaneEntry e{ended, ended, ended, ended};
+    if (valid) fetch_entry(ent, r.i, e);
+    while (walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt)) {}
     best_t = r.best_t;
     best_prim = r.best_prim;
 }
@@ -584,7 +628,7 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+                closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
@@ -834,11 +878,12 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
     bool has_ray = false;
     uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
-    // (a lane without an entry to visit holds TAG_END in the tag word of `a`, as in closest_hit)
+    // (a lane without an entry to visit holds TAG_END in the tag word of e.a, as in closest_hit)
     const float end_word = u2f(TAG_END << TAG_SHIFT);
-    float4 a = make_float4(0.0f, 0.0f, 0.0f, end_word), b = a;
+    const float4 ended = make_float4(0.0f, 0.0f, 0.0f, end_word);
+    LaneEntry e{ended, ended, ended, ended};
     for (;;) {
-        const bool live = (f2u(a.w) >> TAG_SHIFT) != TAG_END;
+        const bool live = (f2u(e.a.w) >> TAG_SHIFT) != TAG_END;
         const unsigned long long m_live = __ballot(live);
         const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
@@ -866,37 +911,13 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
-                    a = ent[r.i]; b = ent[r.i + 1];
+                    fetch_entry(ent, r.i, e);
                 }
                 next = min(n, next + n_idle);
                 continue;
             }
         }
-        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
-        const bool at_box = tag == TAG_BOX;
-        const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
-        const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
-        RT_UTIL_TRIP(cnt);
-        if (at_box) {
-            if (COUNT) cnt.box++;
-            r.i = box_step(a, b, r, t_min);
-            a = ent[r.i]; b = ent[r.i + 1];    // (behind the last entry: the TAG_END units)
-        }
-        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
-            if (at_prim) {
-                if (tag == TAG_TRI) {
-                    if (COUNT) cnt.tri++;
-                    const float4 c = ent[r.i + 2];
-                    tri_step(a, b, c, r, t_min);
-                    r.i = r.i + f2u(c.w);
-                } else {
-                    if (COUNT) cnt.sph++;
-                    sphere_step(a, b, r, t_min);
-                    r.i = r.i + 2;
-                }
-                a = ent[r.i]; b = ent[r.i + 1];
-            }
-        }
+        walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt);
     }
 }
 
@@ -946,7 +967,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             enqueue(kb, ib);
         }
     } else if (SWEEP == 5 || SWEEP == 6) {
-        walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.units, sc.n_units, sc.prim_wait,
+        walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
                             sc.refill, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
                             sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 8) {
@@ -967,11 +988,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, lane, valid, a.x,
                                            a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 4)
-                closest_hit<COUNT>((const float4*)lds_stack, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit<COUNT>((const float4*)lds_stack, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>((const float4*)sc.units, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
                 kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);
@@ -1201,9 +1222,9 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
     const uint32_t wpb = SWEEP == 4 || SWEEP == 6 ? RT_LDS_BLOCK / 64 : RT_WPB;
     const uint32_t seg = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (SWEEP == 4 || SWEEP == 6) {
-        const float4* src = (const float4*)sc.units;
+        const float4* src = (const float4*)sc.walk;
         float4* dst = (float4*)lds_stack;
-        for (uint32_t i = threadIdx.x; i < sc.n_units + UNITS_END; i += RT_LDS_BLOCK) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < sc.n_walk + UNITS_END; i += RT_LDS_BLOCK) dst[i] = src[i];
         __syncthreads();                       // before any wave of the workgroup may leave
     }
     if (seg >= g.n_seg) return;
@@ -1378,7 +1399,7 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
-        const size_t bytes = (size_t)(sc.n_units + UNITS_END) * 16u;
+        const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
         if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
         return check_launch();
     }

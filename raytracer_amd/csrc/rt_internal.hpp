@@ -43,7 +43,8 @@ constexpr uint32_t ORD_FIRST_LOWER = 1u << 31;
 constexpr uint32_t ORDERED_MAX_DEPTH = 64;   // 4 waves x 64 lanes x 64 slots x 4 B = 64 KB of LDS per workgroup
 // the unit array (and each of its octant copies) is followed by this many TAG_END units, where the
 // links of the last entries lead: the per-lane walks fetch their next entry unconditionally
-constexpr uint32_t UNITS_END = 2;
+// (four: a lane fetches up to four units at its cursor)
+constexpr uint32_t UNITS_END = 4;
 constexpr uint32_t KIND_SHIFT = 28;
 constexpr uint32_t MAT_MASK = (1u << KIND_SHIFT) - 1u;
 constexpr uint32_t PRIM_BACKFACE = 1u << 31;       // flag in the compact hit record
@@ -62,6 +63,18 @@ struct FlatScene {
     // links count units.
     std::vector<float> units;
     size_t n_units() const { return units.size() / 4 - UNITS_END; }   // without the end units
+    // The units once more in the order and with the links the reference-order per-lane walks use.
+    // Every entry names its successors itself -- a box `skip` (a.w, where to go when it is missed)
+    // and `child` (b.w, its first child), a triangle `next` (c.w) and a sphere `next` (b.y), all as
+    // unit indices -- so memory order is free, and it is chosen for locality: the children of a box
+    // lie side by side (a box that is hit gets BOTH children tested, so the 64 bytes of a pair of
+    // boxes are one fetch that is used in full), a pair of boxes never straddles a 64-byte
+    // boundary, the first child's own children follow the pair, and the top levels of the trees
+    // come first, breadth first (walk_top_units of them: the part a kernel may keep in LDS).
+    // Entry 0 is at unit 0.  Visiting order and arithmetic are those of `units`.
+    std::vector<float> walk;
+    size_t n_walk() const { return walk.size() / 4 - UNITS_END; }
+    uint32_t walk_top_units = 0;       // units at the front of `walk` laid out breadth first
     uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
     bool ordered_ok = false;           // box entries carry the child links of the ordered walk
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
@@ -88,13 +101,17 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
 // for the rays of that octant (by the axis and order annotate_children recorded), so the plain
 // skip-link walk meets them front to back.  `units` must carry the child links (ordered_ok).
 void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out);   // units as 32-bit words
+// (the copies carry the explicit links of FlatScene::walk -- child, next -- each in its own pre-order)
 
 // ---------------------------------------------------------------------------------------------
 // Device side
 // ---------------------------------------------------------------------------------------------
 struct DevScene {
     const void* entries;      // float4[4 * n_entries] (+ the TAG_END entry): the wave sweep's form
-    const void* units;        // float4[n_units + UNITS_END]: the per-lane walks' form
+    const void* units;        // float4[n_units + UNITS_END]: pre-order units (ordered walk; source of the octant copies)
+    const void* walk;         // float4[n_walk + UNITS_END]: linked units in locality order (reference-order per-lane walks)
+    uint32_t n_walk;
+    uint32_t walk_top_units;  // the first units of `walk` hold the top levels of the trees, breadth first
     const void* prim_geo;     // float4[n_prims]
     const uint32_t* prim_meta;
     const void* materials;    // float4[2 * n_mats]

@@ -95,6 +95,8 @@ extern "C" {
     pub fn rt_scene_get_entries(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
     pub fn rt_scene_num_units(scene: *const rt_scene) -> usize;
     pub fn rt_scene_get_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_scene_num_walk_units(scene: *const rt_scene) -> usize;
+    pub fn rt_scene_get_walk_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
 
     pub fn rt_trace(scene: *mut rt_scene, rays: *const rt_ray, n: usize, t_min: f32, t_max: f32, out: *mut rt_hit) -> c_int;
     pub fn rt_trace_device(scene: *mut rt_scene, d_rays: *const c_void, n: usize, t_min: f32, t_max: f32,

@@ -466,6 +466,98 @@ def test_units_are_the_entries_repacked(rt, ob):
                 assert uu[k + 2, 3] == unit_of[i + 1] - k          # distance to the next entry: 3 or 4
 
 
+def _walk_linked(units, o, d, t_min, t_max):
+    """The device's reference-order per-lane loop over the linked units: a box continues at its
+    child (word 7) or its skip link (word 3), a triangle at word 11, a sphere at word 5."""
+    uu = units.view(np.uint32)
+    n = len(units)
+    visited = []
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        inv = [F(1.0) / d[k] for k in range(3)]
+        best_t, best = F(t_max), 0xFFFFFFFF
+        i = 0
+        while i < n:
+            visited.append(i)
+            tag = int(uu[i, 3] >> 30)
+            e = np.concatenate([units[i], units[i + 1], units[i + 2] if tag == 1 else np.zeros(4, F)])
+            if tag == 0:
+                i = int(uu[i, 3] & 0x3FFFFFFF) if _box_miss(e, o, inv, t_min, best_t) else int(uu[i + 1, 3])
+            else:
+                best_t, best = _prim_test(e, tag, int(uu[i + 1, 3]), o, d, t_min, best_t, best)
+                i = int(uu[i + 2, 3]) if tag == 1 else int(uu[i + 1, 1])
+        assert i == n                                  # every walk ends on the end units, nowhere else
+    return best, best_t, visited
+
+
+@pytest.mark.parametrize("root", [0, 2])
+@pytest.mark.parametrize("top", ["0", "64", "100000"])
+def test_linked_units_keep_the_reference_order(rt, ob, root, top, monkeypatch):
+    """The locality-ordered, explicitly linked units of the per-lane walks: every entry appears once,
+    boxes and spheres are 32-byte aligned, the two children of a box lie side by side and a pair of
+    boxes inside one 64-byte line, and following the links visits exactly the entries, in exactly the
+    order, of the pre-order walk -- whatever part of the tree is laid out breadth first."""
+    monkeypatch.setenv("RT_LAYOUT_TOP", top)
+    mats, objects, _ = random_scene(ob, 51 + root, n_spheres=21, n_meshes=2, tris_per_mesh=37, extent=5.0)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root)
+    ent, units = sc.entries(), sc.walk_units()
+    eu, uu = ent.view(np.uint32), units.view(np.uint32)
+    n = len(ent)
+    # recover pos[] by following child / next links from unit 0 in pre-order
+    pos = {}
+
+    def follow(i, k):                                  # entry i lives at unit k
+        assert i not in pos
+        pos[i] = k
+        tag = int(eu[i, 3] >> 30)
+        assert int(uu[k, 3] >> 30) == tag
+        np.testing.assert_array_equal(units[k, 0:3], ent[i, 0:3])
+        np.testing.assert_array_equal(units[k + 1, 0:(1 if tag == 2 else 3)], ent[i, 4:(5 if tag == 2 else 7)])
+        if tag == 0:
+            assert k % 2 == 0
+            end = int(eu[i, 3] & 0x3FFFFFFF)
+            c, ck = i + 1, int(uu[k + 1, 3])
+            kids = []
+            while c < end:                             # the children sit side by side
+                follow(c, ck)
+                kids.append((c, ck))
+                ctag = int(eu[c, 3] >> 30)
+                nxt = int(uu[ck, 3] & 0x3FFFFFFF) if ctag == 0 else (int(uu[ck + 2, 3]) if ctag == 1 else int(uu[ck + 1, 1]))
+                c = int(eu[c, 3] & 0x3FFFFFFF) if ctag == 0 else c + 1
+                if c < end:
+                    assert nxt - ck in (2, 3, 4)       # the sibling is adjacent (one padding unit at most)
+                    ck = nxt
+                else:
+                    assert nxt == int(uu[k, 3] & 0x3FFFFFFF)     # the last child leaves where its parent does
+            if len(kids) == 2 and all(int(eu[c, 3] >> 30) != 1 for c, _ in kids):
+                assert kids[0][1] // 4 == (kids[1][1] + 1) // 4  # both boxes inside one 64-byte line
+        else:
+            assert uu[k + 1, 3] == eu[i, 7]
+            if tag == 1:
+                np.testing.assert_array_equal(units[k + 2, 0:3], ent[i, 8:11])
+            else:
+                assert k % 2 == 0
+
+    i, k = 0, 0
+    while i < n:                                       # top-level entries
+        follow(i, k)
+        tag = int(eu[i, 3] >> 30)
+        k = int(uu[k, 3] & 0x3FFFFFFF) if tag == 0 else (int(uu[k + 2, 3]) if tag == 1 else int(uu[k + 1, 1]))
+        i = int(eu[i, 3] & 0x3FFFFFFF) if tag == 0 else i + 1
+    assert k == len(units) and sorted(pos) == list(range(n))
+    rays = random_rays(ob, 6, 150, -6.0, 6.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    unit_to_entry = {v: key for key, v in pos.items()}
+    for r in range(len(rays)):
+        prim, t, visited = _walk_linked(units, rays["o"][r], rays["d"][r], F(0.001), F(np.inf))
+        assert prim == want["prim_id"][r]
+        if prim != 0xFFFFFFFF:
+            assert F(t).view(np.uint32) == want["t"][r].view(np.uint32)
+        order = [unit_to_entry[v] for v in visited]
+        assert order == sorted(order)                  # pre-order = the reference's visiting order
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 30
+
+
 def test_progressive_schedule_and_ppm(rt, tmp_path):
     """main.rs:355-356, 409-411: min(10, spp), then doubling, capped at spp."""
     assert rt.progressive_schedule(1) == [1]
