@@ -35,7 +35,7 @@ typedef enum {
     RT_ERR_INVALID = -1,      /* bad argument */
     RT_ERR_DEVICE = -2,       /* HIP runtime failure (no GPU, launch or copy failed) */
     RT_ERR_STATE = -3,        /* call order (scene not committed, already committed, ...) */
-    RT_ERR_UNSUPPORTED = -4,  /* e.g. a non-identity mesh transform */
+    RT_ERR_UNSUPPORTED = -4,  /* e.g. the wave sweep on a scene with transformed meshes */
     RT_ERR_NOMEM = -5
 } rt_status;
 
@@ -152,9 +152,22 @@ void rt_scene_destroy(rt_scene* scene);
 int rt_scene_set_materials(rt_scene* scene, const rt_material* mats, size_t n);
 /* each sphere is one object, appended in order (Vec<Box<dyn Hittable>>, main.rs:100-158) */
 int rt_scene_add_spheres(rt_scene* scene, const rt_sphere* spheres, size_t n);
-/* one Mesh object (Mesh::new, shape.rs:236-257).  xform is a column-major 4x4 or NULL for the
- * identity; only the identity is supported (every shipped scene uses Mat4::identity()). */
+/* one Mesh object (Mesh::new, shape.rs:236-257).  xform is Mesh.transform as a column-major 4x4
+ * (glam's Mat4: x_axis, y_axis, z_axis, w_axis) or NULL for the identity.  With a transform the
+ * mesh is traced as the reference traces it: the tree lives in the mesh's local space, a ray that
+ * reaches the mesh is taken there with the inverse transform (camera.rs:137-142, shape.rs:454),
+ * and the hit point and normal come back through the transform (shape.rs:303-307).  The Mat4
+ * arithmetic is restated from glam's published source and cannot be checked against the
+ * reference here (it ships no scene with a transform).  A scene with transformed meshes is traced
+ * by the per-lane walk only. */
 int rt_scene_add_mesh(rt_scene* scene, const rt_triangle* tris, size_t n, const float* xform);
+/* Containers inside the object list (Bvh.left/right and HittableList.objects hold any Hittable,
+ * shape.rs:55-57, 87-91): the objects added between begin and end are the children of ONE
+ * container object -- Bvh::new(children, axis) for RT_ROOT_BVH, a HittableList for RT_ROOT_LIST --
+ * which is itself a child of the enclosing container (or of the scene's root).  Groups nest.
+ * Primitive ids count spheres and triangles in the order they were added, whatever their nesting. */
+int rt_scene_begin_group(rt_scene* scene, int kind, int axis);
+int rt_scene_end_group(rt_scene* scene);
 int rt_scene_set_root(rt_scene* scene, int root_kind);
 /* How the trees inside meshes are split (before rt_scene_commit).  REFERENCE: Mesh::build_bvh's
  * stable median split on min[axis] (shape.rs:264-290): the reference's visiting order, hits exact
@@ -169,6 +182,19 @@ int rt_scene_set_build(rt_scene* scene, int build_mode);
 /* the build mode of scenes created from now on (process-wide; the scene constructors of
  * rt_host.h create their scenes internally and take it from here) */
 int rt_set_default_build(int build_mode);
+/* Binary scene cache (no counterpart in the reference, whose ingest -- Mesh::from_file and
+ * Mesh::new, shape.rs:236-257, 347-406 -- parses and builds on every start).  With a cache
+ * directory, rt_scene_commit() looks for <dir>/<key>.rtscene, where the key is a 64-bit hash of
+ * everything the flattened arrays depend on (materials, every sphere and triangle, transforms,
+ * containers, root kind, build mode, layout parameters); a complete file of that key is loaded
+ * instead of building the trees, otherwise they are built and the file is written (to a temporary
+ * name first, then renamed, so concurrent processes never see half a file).  The directory must
+ * exist.  rt_set_default_cache_dir() sets the directory of scenes created afterwards (NULL or ""
+ * turns it off), the scene constructors of rt_host.h included. */
+enum { RT_CACHE_OFF = 0, RT_CACHE_STORED = 1, RT_CACHE_LOADED = 2, RT_CACHE_STORE_FAILED = 3 };
+int rt_set_default_cache_dir(const char* dir);
+int rt_scene_set_cache_dir(rt_scene* scene, const char* dir);
+int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CACHE_* */
 /* How the closest-hit kernel walks the flattened trees.  PER_LANE and SWEEP visit the same
  * entries in the same order with the same arithmetic as the reference's recursion
  * (shape.rs:142-158, 292-324) and give bit-identical hits; they differ in speed only.

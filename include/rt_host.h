@@ -22,7 +22,9 @@ typedef struct rt_world rt_world;
 int rt_world_create_world1(rt_context* ctx, rt_world** out);
 /* create_world2() (main.rs:178-241): thing.obj + emissive sphere, Bvh root.
  * variant 0: the shipped material map ({"default"}); variant 1: the "glass + diffuse" map
- * {"Material": dielectric(1,1,1; ior 1.5), "None": lambert(.73)} */
+ * {"Material": dielectric(1,1,1; ior 1.5), "None": lambert(.73)}; variant 2: variant 0 plus the two
+ * planes the reference keeps in a comment (Mesh::plane(2, 2, material1,
+ * Mat4::from_translation((0, 0, -0.5) and (0, 0, 1))), main.rs:195-204) */
 int rt_world_create_world2(rt_context* ctx, const char* thing_obj, int variant, rt_world** out);
 /* create_cornell_box(filename) (main.rs:243-317): the Mesh is the root */
 int rt_world_create_cornell_box(rt_context* ctx, const char* obj_path, rt_world** out);
@@ -46,6 +48,9 @@ size_t rt_world_num_objects(const rt_world* world);
 int rt_world_object_info(const rt_world* world, size_t i, size_t* count);
 int rt_world_get_sphere(const rt_world* world, size_t i, rt_sphere* out);
 int rt_world_get_mesh(const rt_world* world, size_t i, rt_triangle* out);
+/* Mesh.transform of object i, column-major; returns 1 when it is not the identity, 0 when it is
+ * (or the object is a sphere), negative on error */
+int rt_world_get_mesh_xform(const rt_world* world, size_t i, float out[16]);
 int rt_world_root_kind(const rt_world* world);
 
 /* Camera::new + Camera::setup without a world */

@@ -59,6 +59,11 @@ def lib():
         "oracle_scene_set_materials": (None, [vp, vp, sz]),
         "oracle_scene_add_spheres": (None, [vp, vp, sz]),
         "oracle_scene_add_mesh": (None, [vp, vp, sz]),
+        "oracle_scene_add_mesh_xf": (None, [vp, vp, sz, vp]),
+        "oracle_scene_begin_group": (None, [vp, i32, i32]),
+        "oracle_scene_end_group": (None, [vp]),
+        "oracle_mat4_inverse": (None, [vp, vp]),
+        "oracle_mat4_transform": (None, [vp, vp, f32, vp]),
         "oracle_scene_set_root": (None, [vp, i32]),
         "oracle_scene_set_camera": (None, [vp, vp, vp, vp, f32, f32, f32]),
         "oracle_scene_set_sky": (None, [vp, f32]),
@@ -75,6 +80,7 @@ def lib():
         "oracle_scene_object_info": (i32, [vp, sz, C.POINTER(sz)]),
         "oracle_scene_get_sphere": (None, [vp, sz, vp]),
         "oracle_scene_get_mesh": (None, [vp, sz, vp]),
+        "oracle_scene_get_xform": (i32, [vp, sz, vp]),
         "oracle_scene_sky": (f32, [vp]),
         "oracle_scene_root_kind": (i32, [vp]),
         "oracle_scene_camera": (None, [vp, f32, vp]),
@@ -145,13 +151,30 @@ class Scene:
         s = Scene(L.oracle_scene_new())
         m = np.ascontiguousarray(materials, dtype=material_dt)
         L.oracle_scene_set_materials(s.h, _ptr(m), len(m))
-        for kind, arr in objects:
-            if kind == "spheres":
-                a = np.ascontiguousarray(arr, dtype=sphere_dt)
-                L.oracle_scene_add_spheres(s.h, _ptr(a), len(a))
-            else:
-                a = np.ascontiguousarray(arr, dtype=triangle_dt)
-                L.oracle_scene_add_mesh(s.h, _ptr(a), len(a))
+
+        def add(items):
+            """('spheres', arr) | ('mesh', arr[, xform 4x4 column-major]) | ('bvh', [items][, axis]) |
+            ('list', [items]): the last two are container objects whose children are further items."""
+            for item in items:
+                kind, arr = item[0], item[1]
+                if kind == "spheres":
+                    a = np.ascontiguousarray(arr, dtype=sphere_dt)
+                    L.oracle_scene_add_spheres(s.h, _ptr(a), len(a))
+                elif kind == "mesh":
+                    a = np.ascontiguousarray(arr, dtype=triangle_dt)
+                    if len(item) > 2 and item[2] is not None:
+                        x = np.ascontiguousarray(item[2], dtype=np.float32).reshape(16)
+                        L.oracle_scene_add_mesh_xf(s.h, _ptr(a), len(a), _ptr(x))
+                    else:
+                        L.oracle_scene_add_mesh(s.h, _ptr(a), len(a))
+                elif kind in ("bvh", "list"):
+                    L.oracle_scene_begin_group(s.h, ROOT_BVH if kind == "bvh" else ROOT_LIST,
+                                               item[2] if kind == "bvh" and len(item) > 2 else 0)
+                    add(arr)
+                    L.oracle_scene_end_group(s.h)
+                else:
+                    raise ValueError(kind)
+        add(objects)
         L.oracle_scene_set_root(s.h, root_kind)
         if camera is not None:
             f, a, u, vfov, ap, focus = camera
@@ -168,8 +191,8 @@ class Scene:
         return out
 
     def objects(self):
-        """The object list in insertion order, in from_description() form (spheres one by one
-        are merged into runs)."""
+        """The leaf objects in insertion order, in from_description() form (spheres one by one are
+        merged into runs; a transformed mesh carries its matrix; containers are not reproduced)."""
         L = lib()
         out = []
         run = []
@@ -186,7 +209,11 @@ class Scene:
                     run = []
                 tr = np.zeros(cnt.value, dtype=triangle_dt)
                 L.oracle_scene_get_mesh(self.h, i, _ptr(tr))
-                out.append(("mesh", tr))
+                xf = np.zeros(16, dtype=np.float32)
+                if L.oracle_scene_get_xform(self.h, i, _ptr(xf)):
+                    out.append(("mesh", tr, xf))
+                else:
+                    out.append(("mesh", tr))
         if run:
             out.append(("spheres", np.concatenate(run)))
         return out
@@ -298,6 +325,20 @@ def scatter(material, ray_o, ray_d, p, n, front_face, rng_state):
     ok = lib().oracle_scatter(_ptr(m), _ptr(_f3(ray_o)), _ptr(_f3(ray_d)), _ptr(_f3(p)), _ptr(_f3(n)),
                               int(front_face), C.byref(st), _ptr(out))
     return bool(ok), out[0:3].copy(), out[3:6].copy(), out[6:9].copy(), st.value
+
+
+def mat4_inverse(m):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros(16, dtype=np.float32)
+    lib().oracle_mat4_inverse(_ptr(a), _ptr(out))
+    return out
+
+
+def mat4_transform(m, v, w):
+    a = np.ascontiguousarray(m, dtype=np.float32).reshape(16)
+    out = np.zeros(3, dtype=np.float32)
+    lib().oracle_mat4_transform(_ptr(a), _ptr(_f3(v)), w, _ptr(out))
+    return out
 
 
 def rng_state_after_world1():

@@ -66,6 +66,73 @@ constexpr float F32_EPSILON = 1.1920929e-7f;   // f32::EPSILON
 const float F32_INF = std::numeric_limits<float>::infinity();
 
 // ---------------------------------------------------------------------------------------------
+// glam 0.8.7 Mat4 (column-major, four Vec4 columns), as far as Mesh uses it (shape.rs:236-251,
+// 303-307, camera.rs:137-142).  PARITY UNPINNED: restated from the crate's published source --
+// transform_point3 / transform_vector3 = mul_vec4 of (v, 1) / (v, 0) truncated, with mul_vec4 =
+// ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w, every step a rounded f32 operation (the
+// crate's mul_add is a multiply and an add without the `fma` feature); inverse() is the cofactor
+// expansion the crate ports from GLM.  Nothing in the reference (no test, no output: every shipped
+// scene uses Mat4::identity()) can confirm the operation order.
+// ---------------------------------------------------------------------------------------------
+struct Mat4 {
+    float m[16];                               // m[4 * column + row]
+    static Mat4 identity() {
+        Mat4 r{};
+        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+        return r;
+    }
+    bool is_identity() const {
+        const Mat4 i = identity();
+        return std::memcmp(m, i.m, sizeof(m)) == 0;
+    }
+    V3 mul_vec(V3 v, float w) const {
+        float r[3];
+        for (int k = 0; k < 3; k++) {
+            float acc = m[k] * v.x;
+            acc = m[4 + k] * v.y + acc;
+            acc = m[8 + k] * v.z + acc;
+            acc = m[12 + k] * w + acc;
+            r[k] = acc;
+        }
+        return V3{r[0], r[1], r[2]};
+    }
+    V3 transform_point3(V3 v) const { return mul_vec(v, 1.0f); }
+    V3 transform_vector3(V3 v) const { return mul_vec(v, 0.0f); }
+    Mat4 inverse() const {
+        const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+        const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+        const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+        const float m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+        const float coef00 = m22 * m33 - m32 * m23, coef02 = m12 * m33 - m32 * m13, coef03 = m12 * m23 - m22 * m13;
+        const float coef04 = m21 * m33 - m31 * m23, coef06 = m11 * m33 - m31 * m13, coef07 = m11 * m23 - m21 * m13;
+        const float coef08 = m21 * m32 - m31 * m22, coef10 = m11 * m32 - m31 * m12, coef11 = m11 * m22 - m21 * m12;
+        const float coef12 = m20 * m33 - m30 * m23, coef14 = m10 * m33 - m30 * m13, coef15 = m10 * m23 - m20 * m13;
+        const float coef16 = m20 * m32 - m30 * m22, coef18 = m10 * m32 - m30 * m12, coef19 = m10 * m22 - m20 * m12;
+        const float coef20 = m20 * m31 - m30 * m21, coef22 = m10 * m31 - m30 * m11, coef23 = m10 * m21 - m20 * m11;
+        const float fac0[4] = {coef00, coef00, coef02, coef03}, fac1[4] = {coef04, coef04, coef06, coef07};
+        const float fac2[4] = {coef08, coef08, coef10, coef11}, fac3[4] = {coef12, coef12, coef14, coef15};
+        const float fac4[4] = {coef16, coef16, coef18, coef19}, fac5[4] = {coef20, coef20, coef22, coef23};
+        const float vec0[4] = {m10, m00, m00, m00}, vec1[4] = {m11, m01, m01, m01};
+        const float vec2[4] = {m12, m02, m02, m02}, vec3_[4] = {m13, m03, m03, m03};
+        const float sign_a[4] = {1.0f, -1.0f, 1.0f, -1.0f}, sign_b[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+        float inv[4][4];
+        for (int k = 0; k < 4; k++) {
+            inv[0][k] = ((vec1[k] * fac0[k] - vec2[k] * fac1[k]) + vec3_[k] * fac2[k]) * sign_a[k];
+            inv[1][k] = ((vec0[k] * fac0[k] - vec2[k] * fac3[k]) + vec3_[k] * fac4[k]) * sign_b[k];
+            inv[2][k] = ((vec0[k] * fac1[k] - vec1[k] * fac3[k]) + vec3_[k] * fac5[k]) * sign_a[k];
+            inv[3][k] = ((vec0[k] * fac2[k] - vec1[k] * fac4[k]) + vec2[k] * fac5[k]) * sign_b[k];
+        }
+        const float d0 = m00 * inv[0][0], d1 = m01 * inv[1][0], d2 = m02 * inv[2][0], d3 = m03 * inv[3][0];
+        const float det = (d0 + d1) + (d2 + d3);
+        const float rcp = 1.0f / det;
+        Mat4 r;
+        for (int c = 0; c < 4; c++)
+            for (int k = 0; k < 4; k++) r.m[4 * c + k] = inv[c][k] * rcp;
+        return r;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // math.rs:4-80  RandomSeries
 // ---------------------------------------------------------------------------------------------
 struct RandomSeries {
@@ -171,10 +238,11 @@ struct Aabb {
     Aabb surrounding_point(V3 p) const { return Aabb{vmin(min, p), vmax(max, p)}; }
 };
 
-// camera.rs:126-143 (transform is the identity in every shipped scene and is not restated)
+// camera.rs:126-143
 struct Ray {
     V3 origin, dir;
     V3 at(float t) const { return origin + dir * t; }
+    Ray transform(const Mat4& t) const { return Ray{t.transform_point3(origin), t.transform_vector3(dir)}; }
 };
 
 // camera.rs:92-124, plus the primitive id and material index the reference does not expose
@@ -397,6 +465,12 @@ struct Mesh : Hittable {                       // shape.rs:209-324, 452-494
     std::vector<Triangle> triangles;
     std::vector<Node> bvh_nodes;
     Aabb aabb;
+    // A mesh whose transform is bit for bit Mat4::identity() (every shipped scene) skips the
+    // transform arithmetic: for finite vectors it changes nothing except that a -0.0 component
+    // may come out as +0.0, which can flip the sign of inv_d (math.rs:152-156) for a ray with a
+    // negative-zero direction component; hit parity is not claimed for such rays.
+    Mat4 transform = Mat4::identity(), inverse_transform = Mat4::identity();
+    bool transformed = false;
 
     static Aabb compute_aabb(const std::vector<Triangle>& tris) {      // shape.rs:218-233
         Aabb a = Aabb::infinity();
@@ -406,10 +480,15 @@ struct Mesh : Hittable {                       // shape.rs:209-324, 452-494
         a.min.x -= 0.0001f; a.min.y -= 0.0001f; a.min.z -= 0.0001f;
         return a;
     }
-    explicit Mesh(std::vector<Triangle> tris) : triangles(std::move(tris)) {   // shape.rs:236-257
+    explicit Mesh(std::vector<Triangle> tris, const Mat4& xf = Mat4::identity()) : triangles(std::move(tris)) {   // shape.rs:236-257
+        transformed = !xf.is_identity();
+        if (transformed) { transform = xf; inverse_transform = xf.inverse(); }
         aabb = Aabb::infinity();
         for (const Triangle& t : triangles)
-            aabb = aabb.surrounding_point(t.p1).surrounding_point(t.p2).surrounding_point(t.p3);
+            aabb = transformed ? aabb.surrounding_point(transform.transform_point3(t.p1))
+                                     .surrounding_point(transform.transform_point3(t.p2))
+                                     .surrounding_point(transform.transform_point3(t.p3))
+                               : aabb.surrounding_point(t.p1).surrounding_point(t.p2).surrounding_point(t.p3);
         bvh_nodes.reserve(triangles.size() * 2 + 1);
         build_bvh(triangles, 0);
     }
@@ -453,8 +532,10 @@ struct Mesh : Hittable {                       // shape.rs:209-324, 452-494
                 V3 hit_normal = tr.n1;
                 if (backface) hit_normal = hit_normal * -1.0f;
                 hit.t = t;
-                hit.p = ray.at(t);
-                hit.set_face_normal(ray, normalize(hit_normal));
+                // shape.rs:303-307: the point and the normal go through the transform; the facing test
+                // uses the LOCAL ray (the parameter shadows the caller's) against the WORLD normal
+                hit.p = transformed ? transform.transform_point3(ray.at(t)) : ray.at(t);
+                hit.set_face_normal(ray, normalize(transformed ? transform.transform_vector3(hit_normal) : hit_normal));
                 hit.material = tr.material_index;
                 hit.prim_id = tr.prim_id;
                 return true;
@@ -469,6 +550,7 @@ struct Mesh : Hittable {                       // shape.rs:209-324, 452-494
         return false;
     }
     bool hit(const Ray& ray, float t_min, float t_max, Hit& hit) const override {   // shape.rs:453-455
+        if (transformed) return bvh_hit(bvh_nodes.size() - 1, ray.transform(inverse_transform), t_min, t_max, hit);
         return bvh_hit(bvh_nodes.size() - 1, ray, t_min, t_max, hit);
     }
     Aabb get_aabb() const override { return aabb; }
@@ -582,6 +664,14 @@ struct oracle_scene {
     std::unique_ptr<Hittable> root_owner;
     const Hittable* root = nullptr;
     int root_kind = ORACLE_ROOT_BVH;
+    // Containers inside the object list (a Bvh or HittableList whose children are further
+    // objects, shape.rs:55-57, 87-91): items >= 0 name objects[], items < 0 name groups[-1 - item].
+    // groups[0] is the top level (World.hittable's children).
+    struct Group { int kind; int axis; std::vector<long> items; };
+    std::vector<Group> groups{Group{ORACLE_ROOT_BVH, 0, {}}};
+    std::vector<size_t> open_groups{0};
+    std::vector<std::unique_ptr<Hittable>> containers;
+    std::vector<Mat4> mesh_xforms;                     // per object (identity for spheres)
     Camera camera;
     float sky_intensity = 1.0f;
     uint32_t next_prim = 0;
@@ -597,16 +687,20 @@ Material make_material(const oracle_material& m) {
 void add_sphere(oracle_scene* s, V3 c, float r, int mat) {
     auto sp = std::make_unique<Sphere>();
     sp->center = c; sp->radius = r; sp->material = mat; sp->prim_id = s->next_prim++;
+    s->groups[s->open_groups.back()].items.push_back((long)s->objects.size());
     s->objects.push_back(std::move(sp));
     s->object_kind.push_back(0);
+    s->mesh_xforms.push_back(Mat4::identity());
     s->n_spheres++;
 }
 
-void add_mesh(oracle_scene* s, std::vector<Triangle> tris) {
+void add_mesh(oracle_scene* s, std::vector<Triangle> tris, const Mat4& xf = Mat4::identity()) {
     for (Triangle& t : tris) t.prim_id = s->next_prim++;
     s->n_tris += tris.size();
-    s->objects.push_back(std::make_unique<Mesh>(std::move(tris)));
+    s->groups[s->open_groups.back()].items.push_back((long)s->objects.size());
+    s->objects.push_back(std::make_unique<Mesh>(std::move(tris), xf));
     s->object_kind.push_back(1);
+    s->mesh_xforms.push_back(xf);
 }
 
 // shape.rs:347-406
@@ -635,9 +729,27 @@ bool mesh_from_file(oracle_scene* s, const std::string& path, const std::map<std
     return true;
 }
 
+// the Hittable a group's item stands for; inner groups are built first (Bvh::new / HittableList of
+// their own children), exactly as a caller nests the reference's constructors
+const Hittable* build_item(oracle_scene* s, long item) {
+    if (item >= 0) return s->objects[(size_t)item].get();
+    const oracle_scene::Group& g = s->groups[(size_t)(-1 - item)];
+    std::vector<const Hittable*> kids;
+    for (long it : g.items) kids.push_back(build_item(s, it));
+    if (g.kind == ORACLE_ROOT_LIST) {
+        auto l = std::make_unique<HittableList>();
+        l->objects = kids;
+        s->containers.push_back(std::move(l));
+    } else {
+        s->containers.push_back(std::make_unique<Bvh>(kids, g.axis));
+    }
+    return s->containers.back().get();
+}
+
 void commit(oracle_scene* s) {
     std::vector<const Hittable*> objs;
-    for (auto& o : s->objects) objs.push_back(o.get());
+    s->containers.clear();
+    for (long it : s->groups[0].items) objs.push_back(build_item(s, it));
     s->root_owner.reset();
     if (s->root_kind == ORACLE_ROOT_SINGLE && objs.size() == 1) {
         s->root = objs[0];
@@ -784,6 +896,40 @@ void oracle_scene_add_mesh(oracle_scene* s, const oracle_triangle* t, size_t n) 
     }
     add_mesh(s, std::move(tris));
 }
+void oracle_scene_add_mesh_xf(oracle_scene* s, const oracle_triangle* t, size_t n, const float xform[16]) {
+    std::vector<Triangle> tris(n);
+    for (size_t i = 0; i < n; i++) {
+        tris[i].p1 = v3(t[i].p[0][0], t[i].p[0][1], t[i].p[0][2]);
+        tris[i].p2 = v3(t[i].p[1][0], t[i].p[1][1], t[i].p[1][2]);
+        tris[i].p3 = v3(t[i].p[2][0], t[i].p[2][1], t[i].p[2][2]);
+        tris[i].n1 = v3(t[i].n0[0], t[i].n0[1], t[i].n0[2]);
+        tris[i].material_index = (int)t[i].mat;
+        tris[i].prim_id = 0;
+    }
+    Mat4 m = Mat4::identity();
+    if (xform) std::memcpy(m.m, xform, sizeof(m.m));
+    add_mesh(s, std::move(tris), m);
+}
+void oracle_scene_begin_group(oracle_scene* s, int kind, int axis) {
+    s->groups.push_back(oracle_scene::Group{kind, axis, {}});
+    s->groups[s->open_groups.back()].items.push_back(-1 - (long)(s->groups.size() - 1));
+    s->open_groups.push_back(s->groups.size() - 1);
+}
+void oracle_scene_end_group(oracle_scene* s) {
+    if (s->open_groups.size() > 1) s->open_groups.pop_back();
+}
+void oracle_mat4_inverse(const float m[16], float out[16]) {
+    Mat4 a;
+    std::memcpy(a.m, m, sizeof(a.m));
+    const Mat4 r = a.inverse();
+    std::memcpy(out, r.m, sizeof(r.m));
+}
+void oracle_mat4_transform(const float m[16], const float v[3], float w, float out[3]) {
+    Mat4 a;
+    std::memcpy(a.m, m, sizeof(a.m));
+    const V3 r = a.mul_vec(v3(v[0], v[1], v[2]), w);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
 void oracle_scene_set_root(oracle_scene* s, int k) { s->root_kind = k; }
 void oracle_scene_set_camera(oracle_scene* s, const float f[3], const float a[3], const float u[3],
                              float vfov, float aperture, float focus) {
@@ -831,10 +977,24 @@ oracle_scene* oracle_create_world1(void) {     // main.rs:75-176
 oracle_scene* oracle_create_world2(const char* thing_obj, int variant) {   // main.rs:178-241
     oracle_scene* s = new oracle_scene();
     std::map<std::string, int> mm;
-    if (variant == 0) {
+    if (variant == 0 || variant == 2) {
         s->materials = {Material{ORACLE_LAMBERT, v3(1, 1, 1), 0.0f, false},
                         Material{ORACLE_EMISSIVE, splat(4.0f), 0.0f, false}};
         mm["default"] = 0;
+        if (variant == 2) {                    // the two planes main.rs:195-204 keeps in a comment
+            for (float z : {-0.5f, 1.0f}) {    // Mesh::plane(2.0, 2.0, material1, Mat4::from_translation(..)), shape.rs:326-345
+                const float w = 2.0f, h = 2.0f;
+                Triangle a, b;
+                a.p1 = v3(-w, -h, 0); a.p2 = v3(-w, h, 0); a.p3 = v3(w, -h, 0);
+                b.p1 = v3(w, -h, 0); b.p2 = v3(-w, h, 0); b.p3 = v3(w, h, 0);
+                a.n1 = b.n1 = v3(0, 0, 1);
+                a.material_index = b.material_index = 0;
+                a.prim_id = b.prim_id = 0;
+                Mat4 m = Mat4::identity();
+                m.m[12] = 0.0f; m.m[13] = 0.0f; m.m[14] = z;
+                add_mesh(s, {a, b}, m);
+            }
+        }
     } else {
         // the "glass + diffuse" material map: same geometry, MTL names mapped explicitly
         s->materials = {Material{ORACLE_LAMBERT, splat(0.73f), 0.0f, false},
@@ -905,6 +1065,11 @@ void oracle_scene_get_mesh(const oracle_scene* s, size_t obj, oracle_triangle* o
         out[i].n0[0] = t.n1.x; out[i].n0[1] = t.n1.y; out[i].n0[2] = t.n1.z;
         out[i].mat = (uint32_t)t.material_index;
     }
+}
+int oracle_scene_get_xform(const oracle_scene* s, size_t obj, float out[16]) {
+    const Mat4& m = s->mesh_xforms[obj];
+    std::memcpy(out, m.m, sizeof(m.m));
+    return m.is_identity() ? 0 : 1;
 }
 float oracle_scene_sky(const oracle_scene* s) { return s->sky_intensity; }
 int oracle_scene_root_kind(const oracle_scene* s) { return s->root_kind; }

@@ -63,8 +63,19 @@ oracle_scene* oracle_scene_new(void);
 void oracle_scene_free(oracle_scene*);
 void oracle_scene_set_materials(oracle_scene*, const oracle_material*, size_t n);
 void oracle_scene_add_spheres(oracle_scene*, const oracle_sphere*, size_t n);
-/* one Mesh (identity transform) */
+/* one Mesh with the identity transform */
 void oracle_scene_add_mesh(oracle_scene*, const oracle_triangle*, size_t n);
+/* one Mesh with a transform (column-major 4x4, glam Mat4 order; NULL = identity): shape.rs:236-257 */
+void oracle_scene_add_mesh_xf(oracle_scene*, const oracle_triangle*, size_t n, const float xform[16]);
+/* Objects added between begin and end are the children of ONE container object -- a Bvh
+ * (kind ORACLE_ROOT_BVH, built with Bvh::new(children, axis), shape.rs:94) or a HittableList
+ * (ORACLE_ROOT_LIST) -- which itself is a child of the enclosing container; groups nest.
+ * Primitive ids count leaf objects in the order they were added, whatever their nesting. */
+void oracle_scene_begin_group(oracle_scene*, int kind, int axis);
+void oracle_scene_end_group(oracle_scene*);
+/* glam Mat4::inverse / transform_point3 (w = 1) / transform_vector3 (w = 0) as restated here */
+void oracle_mat4_inverse(const float m[16], float out[16]);
+void oracle_mat4_transform(const float m[16], const float v[3], float w, float out[3]);
 void oracle_scene_set_root(oracle_scene*, int root_kind);
 void oracle_scene_set_camera(oracle_scene*, const float look_from[3], const float look_at[3],
                              const float vup[3], float vfov, float aperture, float focus_dist);
@@ -74,7 +85,8 @@ int oracle_scene_commit(oracle_scene*);
 
 /* ---- the reference's scene constructors ---- */
 oracle_scene* oracle_create_world1(void);                          /* main.rs:75-176  */
-/* variant 0: as shipped (all "default" lambert); variant 1: Material->glass 1.5, None->lambert .73 */
+/* variant 0: as shipped (all "default" lambert); variant 1: Material->glass 1.5, None->lambert .73;
+ * variant 2: as shipped plus the two translated planes main.rs:195-204 keeps in a comment */
 oracle_scene* oracle_create_world2(const char* thing_obj, int variant);   /* main.rs:178-241 */
 oracle_scene* oracle_create_cornell_box(const char* obj_path);    /* main.rs:243-317 */
 
@@ -89,6 +101,8 @@ void oracle_scene_get_materials(const oracle_scene*, oracle_material* out);
 int oracle_scene_object_info(const oracle_scene*, size_t i, size_t* count);
 void oracle_scene_get_sphere(const oracle_scene*, size_t obj, oracle_sphere* out);
 void oracle_scene_get_mesh(const oracle_scene*, size_t obj, oracle_triangle* out);
+/* the transform of object obj (identity for spheres); returns 1 when it is not the identity */
+int oracle_scene_get_xform(const oracle_scene*, size_t obj, float out[16]);
 float oracle_scene_sky(const oracle_scene*);
 int oracle_scene_root_kind(const oracle_scene*);
 /* Camera::setup(aspect) (camera.rs:55-78) then the post-setup fields */

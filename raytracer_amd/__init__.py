@@ -29,6 +29,7 @@ MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSAL_OCTANT = 0, 1, 2, 3, 4
 BUILD_REFERENCE, BUILD_SAH = 0, 1
+CACHE_OFF, CACHE_STORED, CACHE_LOADED, CACHE_STORE_FAILED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
 FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill")
@@ -96,10 +97,15 @@ def _load():
         "rt_scene_set_materials": (i32, [vp, vp, sz]),
         "rt_scene_add_spheres": (i32, [vp, vp, sz]),
         "rt_scene_add_mesh": (i32, [vp, vp, sz, vp]),
+        "rt_scene_begin_group": (i32, [vp, i32, i32]),
+        "rt_scene_end_group": (i32, [vp]),
         "rt_scene_set_root": (i32, [vp, i32]),
         "rt_scene_set_traversal": (i32, [vp, i32]),
         "rt_scene_set_build": (i32, [vp, i32]),
         "rt_set_default_build": (i32, [i32]),
+        "rt_set_default_cache_dir": (i32, [C.c_char_p]),
+        "rt_scene_set_cache_dir": (i32, [vp, C.c_char_p]),
+        "rt_scene_cache_state": (i32, [vp]),
         "rt_scene_commit": (i32, [vp]),
         "rt_scene_num_prims": (sz, [vp]),
         "rt_scene_num_entries": (sz, [vp]),
@@ -133,6 +139,7 @@ def _load():
         "rt_world_object_info": (i32, [vp, sz, C.POINTER(sz)]),
         "rt_world_get_sphere": (i32, [vp, sz, vp]),
         "rt_world_get_mesh": (i32, [vp, sz, vp]),
+        "rt_world_get_mesh_xform": (i32, [vp, sz, vp]),
         "rt_world_root_kind": (i32, [vp]),
         "rt_camera_setup": (i32, [vp, vp, vp, f32, f32, f32, f32, vp]),
         "rt_world_render": (i32, [vp, u32, u32, u32, u32, C.c_uint64, vp, C.POINTER(Stats)]),
@@ -153,8 +160,8 @@ ABI_SYMBOLS = [
     "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_destroy", "rt_last_error",
     "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
-    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
-    "rt_scene_set_traversal", "rt_scene_commit",
+    "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
+    "rt_scene_set_traversal", "rt_set_default_cache_dir", "rt_scene_set_cache_dir", "rt_scene_cache_state", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
     "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_trace",
     "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
@@ -163,7 +170,7 @@ HOST_SYMBOLS = [
     "rt_world_create_world1", "rt_world_create_world2", "rt_world_create_cornell_box",
     "rt_world_create_soup", "rt_world_destroy", "rt_world_scene", "rt_world_sky_intensity",
     "rt_world_camera", "rt_world_num_materials", "rt_world_get_materials", "rt_world_num_objects",
-    "rt_world_object_info", "rt_world_get_sphere", "rt_world_get_mesh", "rt_world_root_kind",
+    "rt_world_object_info", "rt_world_get_sphere", "rt_world_get_mesh", "rt_world_get_mesh_xform", "rt_world_root_kind",
     "rt_camera_setup", "rt_world_render", "rt_obj_count", "rt_progressive_schedule",
     "rt_world_render_progressive", "rt_write_ppm",
 ]
@@ -257,7 +264,7 @@ class Scene:
         s._borrowed = True
         return s
 
-    def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH, build=None):
+    def __init__(self, ctx, materials, objects, root_kind=ROOT_BVH, build=None, _leave_open=False, cache_dir=None):
         self.ctx = ctx
         self._borrowed = False
         h = C.c_void_p()
@@ -266,18 +273,35 @@ class Scene:
         _live.add(self)
         m = np.ascontiguousarray(materials, dtype=material_dt)
         _check(lib.rt_scene_set_materials(self.h, _ptr(m), len(m)))
-        for kind, arr in objects:
-            if kind == "spheres":
-                a = np.ascontiguousarray(arr, dtype=sphere_dt)
-                _check(lib.rt_scene_add_spheres(self.h, _ptr(a), len(a)))
-            elif kind == "mesh":
-                a = np.ascontiguousarray(arr, dtype=triangle_dt)
-                _check(lib.rt_scene_add_mesh(self.h, _ptr(a), len(a), None))
-            else:
-                raise ValueError(kind)
+        def add(items):
+            """('spheres', arr) | ('mesh', arr[, xform 4x4 column-major]) | ('bvh', [items][, axis]) |
+            ('list', [items]): the last two are container objects whose children are further items."""
+            for item in items:
+                kind, arr = item[0], item[1]
+                if kind == "spheres":
+                    a = np.ascontiguousarray(arr, dtype=sphere_dt)
+                    _check(lib.rt_scene_add_spheres(self.h, _ptr(a), len(a)))
+                elif kind == "mesh":
+                    a = np.ascontiguousarray(arr, dtype=triangle_dt)
+                    x = None
+                    if len(item) > 2 and item[2] is not None:
+                        x = np.ascontiguousarray(item[2], dtype=np.float32).reshape(16)
+                    _check(lib.rt_scene_add_mesh(self.h, _ptr(a), len(a), _ptr(x) if x is not None else None))
+                elif kind in ("bvh", "list"):
+                    _check(lib.rt_scene_begin_group(self.h, ROOT_BVH if kind == "bvh" else ROOT_LIST,
+                                                    item[2] if kind == "bvh" and len(item) > 2 else 0))
+                    add(arr)
+                    _check(lib.rt_scene_end_group(self.h))
+                else:
+                    raise ValueError(kind)
+        add(objects)
+        if _leave_open:                        # (tests: a container that is never closed)
+            _check(lib.rt_scene_begin_group(self.h, ROOT_BVH, 0))
         _check(lib.rt_scene_set_root(self.h, root_kind))
         if build is not None:
             _check(lib.rt_scene_set_build(self.h, build))
+        if cache_dir is not None:
+            _check(lib.rt_scene_set_cache_dir(self.h, str(cache_dir).encode()))
         _check(lib.rt_scene_commit(self.h))
 
     def close(self):
@@ -291,6 +315,11 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+    @property
+    def cache_state(self):
+        """What the commit did with the scene cache: CACHE_OFF / STORED / LOADED / STORE_FAILED."""
+        return lib.rt_scene_cache_state(self.h)
 
     def set_traversal(self, mode):
         _check(lib.rt_scene_set_traversal(self.h, mode))
@@ -462,7 +491,11 @@ class World:
                     run = []
                 tr = np.zeros(cnt.value, dtype=triangle_dt)
                 _check(lib.rt_world_get_mesh(self.h, i, _ptr(tr)))
-                out.append(("mesh", tr))
+                xf = np.zeros(16, dtype=np.float32)
+                has = lib.rt_world_get_mesh_xform(self.h, i, _ptr(xf))
+                if has < 0:
+                    _check(has)
+                out.append(("mesh", tr, xf) if has else ("mesh", tr))
         if run:
             out.append(("spheres", np.concatenate(run)))
         return out
@@ -501,6 +534,11 @@ def partition_params(params, n_ranks, rank):
     p = RenderParams.from_buffer_copy(params)
     _check(lib.rt_partition(n_ranks, rank, C.byref(p)))
     return p
+
+
+def set_default_cache_dir(path):
+    """Directory of the binary scene cache for scenes created from now on (None turns it off)."""
+    _check(lib.rt_set_default_cache_dir(str(path).encode() if path else None))
 
 
 def set_default_build(mode):

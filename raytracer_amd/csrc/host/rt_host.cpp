@@ -128,6 +128,13 @@ int rt_world_get_mesh(const rt_world* w, size_t i, rt_triangle* out) {
     return RT_OK;
     RT_HOST_GUARD_END("rt_world_get_mesh")
 }
+int rt_world_get_mesh_xform(const rt_world* w, size_t i, float out[16]) {
+    if (!w || !out || i >= w->renderer->description().objects.size()) return host_fail("rt_world_get_mesh_xform: bad argument");
+    const auto& o = w->renderer->description().objects[i];
+    static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    std::memcpy(out, o.has_xform ? o.xform : ident, sizeof(ident));
+    return o.has_xform ? 1 : 0;
+}
 int rt_world_root_kind(const rt_world* w) { return w ? w->renderer->description().root_kind : -1; }
 
 int rt_camera_setup(const float f[3], const float a[3], const float u[3], float vfov, float aperture,

@@ -72,6 +72,11 @@ Mat4 Mat4::from_translation(Vec3 t) {
     r.m[12] = t.x; r.m[13] = t.y; r.m[14] = t.z;
     return r;
 }
+Mat4 Mat4::from_scale(Vec3 s) {
+    Mat4 r = identity();
+    r.m[0] = s.x; r.m[5] = s.y; r.m[10] = s.z;
+    return r;
+}
 bool Mat4::is_identity() const {
     const Mat4 i = identity();
     return std::memcmp(m, i.m, sizeof(m)) == 0;
@@ -161,6 +166,13 @@ World create_world2(const std::string& thing_obj, int variant) {
         map.push_back({"Material", std::make_shared<DielectricMaterial>(Vec3::one(), 1.5f)});
     }
     std::vector<HittableBox> objects;
+    if (variant == 2) {                        // main.rs:195-204, commented out in the reference
+        map.clear();
+        auto material1 = std::make_shared<LambertianMaterial>(Vec3::one(), false);
+        map.push_back({"default", material1});
+        objects.push_back(Mesh::plane(2.0f, 2.0f, material1, Mat4::from_translation(Vec3(0.0f, 0.0f, -0.5f))));
+        objects.push_back(Mesh::plane(2.0f, 2.0f, material1, Mat4::from_translation(Vec3(0.0f, 0.0f, 1.0f))));
+    }
     objects.push_back(Mesh::from_file(thing_obj, map, Mat4::identity()));
     objects.push_back(std::make_unique<Sphere>(Vec3(0.0f, 0.0f, 1.5f), 0.65f, material_glow));
     World w;
@@ -246,6 +258,10 @@ struct Describer {
         mat_index[m.get()] = i;
         return i;
     }
+    void leaf(SceneDescription::Object&& o) {
+        d.steps.push_back(SceneDescription::Step{SceneDescription::Step::OBJECT, d.objects.size(), 0, 0});
+        d.objects.push_back(std::move(o));
+    }
     void object(const Hittable& h) {
         if (const Sphere* s = dynamic_cast<const Sphere*>(&h)) {
             SceneDescription::Object o;
@@ -253,12 +269,14 @@ struct Describer {
             o.sphere.c[0] = s->center.x; o.sphere.c[1] = s->center.y; o.sphere.c[2] = s->center.z;
             o.sphere.r = s->radius;
             o.sphere.mat = material(s->material);
-            d.objects.push_back(std::move(o));
+            leaf(std::move(o));
         } else if (const Mesh* m = dynamic_cast<const Mesh*>(&h)) {
-            if (!m->transform.is_identity())
-                throw std::runtime_error("Mesh transforms other than the identity are not supported");
             SceneDescription::Object o;
             o.is_mesh = true;
+            if (!m->transform.is_identity()) {
+                o.has_xform = true;
+                std::memcpy(o.xform, m->transform.m, sizeof(o.xform));
+            }
             std::vector<uint32_t> local(m->materials.size());
             for (size_t i = 0; i < local.size(); i++) local[i] = material(m->materials[i]);
             o.tris.resize(m->triangles.size());
@@ -272,9 +290,17 @@ struct Describer {
                 if (t.material_index >= local.size()) throw std::runtime_error("triangle material index out of range");
                 r.mat = local[t.material_index];
             }
-            d.objects.push_back(std::move(o));
+            leaf(std::move(o));
+        } else if (const Bvh* b = dynamic_cast<const Bvh*>(&h)) {          // a container inside a container
+            d.steps.push_back(SceneDescription::Step{SceneDescription::Step::BEGIN_GROUP, 0, RT_ROOT_BVH, b->axis});
+            for (const HittableBox& c : b->objects) object(*c);
+            d.steps.push_back(SceneDescription::Step{SceneDescription::Step::END_GROUP, 0, 0, 0});
+        } else if (const HittableList* l = dynamic_cast<const HittableList*>(&h)) {
+            d.steps.push_back(SceneDescription::Step{SceneDescription::Step::BEGIN_GROUP, 0, RT_ROOT_LIST, 0});
+            for (const HittableBox& c : l->objects) object(*c);
+            d.steps.push_back(SceneDescription::Step{SceneDescription::Step::END_GROUP, 0, 0, 0});
         } else {
-            throw std::runtime_error("nested Bvh / HittableList objects are not supported");
+            throw std::runtime_error("unknown Hittable");
         }
     }
 };
@@ -286,6 +312,7 @@ SceneDescription describe(const World& world) {
     Describer ds{d, {}};
     if (!world.hittable) throw std::runtime_error("World without a hittable");
     if (const Bvh* b = dynamic_cast<const Bvh*>(world.hittable.get())) {
+        if (b->axis != 0) throw std::runtime_error("the root Bvh starts at axis 0 (Bvh::new(objects, 0), main.rs:170, 234)");
         d.root_kind = RT_ROOT_BVH;
         for (const HittableBox& o : b->objects) ds.object(*o);
     } else if (const HittableList* l = dynamic_cast<const HittableList*>(world.hittable.get())) {
@@ -305,8 +332,11 @@ GpuRenderer::GpuRenderer(rt_context* ctx, World world) : ctx_(ctx), world_(std::
     ok(rt_scene_create(ctx, &scene_));
     try {
         ok(rt_scene_set_materials(scene_, desc_.materials.data(), desc_.materials.size()));
-        for (const SceneDescription::Object& o : desc_.objects) {
-            if (o.is_mesh) ok(rt_scene_add_mesh(scene_, o.tris.data(), o.tris.size(), nullptr));
+        for (const SceneDescription::Step& st : desc_.steps) {
+            if (st.kind == SceneDescription::Step::BEGIN_GROUP) { ok(rt_scene_begin_group(scene_, st.group_kind, st.axis)); continue; }
+            if (st.kind == SceneDescription::Step::END_GROUP) { ok(rt_scene_end_group(scene_)); continue; }
+            const SceneDescription::Object& o = desc_.objects[st.object];
+            if (o.is_mesh) ok(rt_scene_add_mesh(scene_, o.tris.data(), o.tris.size(), o.has_xform ? o.xform : nullptr));
             else ok(rt_scene_add_spheres(scene_, &o.sphere, 1));
         }
         ok(rt_scene_set_root(scene_, desc_.root_kind));

@@ -101,6 +101,7 @@ struct Mat4 {
     float m[16];                               // column-major
     static Mat4 identity();
     static Mat4 from_translation(Vec3 t);
+    static Mat4 from_scale(Vec3 s);
     bool is_identity() const;
 };
 
@@ -139,7 +140,8 @@ struct HittableList : Hittable {               // shape.rs:55-57
 
 struct Bvh : Hittable {                        // shape.rs:87-91; the tree itself is built by the GPU library
     std::vector<HittableBox> objects;
-    explicit Bvh(std::vector<HittableBox> o) : objects(std::move(o)) {}
+    int axis = 0;                              // Bvh::new(objects, axis), shape.rs:94
+    explicit Bvh(std::vector<HittableBox> o, int axis_ = 0) : objects(std::move(o)), axis(axis_) {}
 };
 
 struct World {                                 // main.rs:69-73
@@ -150,6 +152,8 @@ struct World {                                 // main.rs:69-73
 
 // main.rs:75-317
 World create_world1();
+// variant 0: as shipped; 1: the glass + diffuse material map; 2: as shipped plus the two planes the
+// reference keeps in a comment (Mesh::plane with Mat4::from_translation, main.rs:195-204)
 World create_world2(const std::string& thing_obj, int variant = 0);
 World create_cornell_box(const std::string& filename);
 World create_soup(uint64_t n_tris, uint32_t grid, uint32_t seed);
@@ -158,11 +162,17 @@ World create_soup(uint64_t n_tris, uint32_t grid, uint32_t seed);
 struct SceneDescription {
     std::vector<rt_material> materials;
     // n_tris stays the mesh's triangle count after `tris` has been released (big meshes, once committed)
-    struct Object { bool is_mesh; rt_sphere sphere; std::vector<rt_triangle> tris; size_t n_tris = 0; bool released = false; };
-    std::vector<Object> objects;
+    struct Object {
+        bool is_mesh; rt_sphere sphere; std::vector<rt_triangle> tris; size_t n_tris = 0; bool released = false;
+        bool has_xform = false; float xform[16] = {};       // Mesh.transform when it is not the identity
+    };
+    std::vector<Object> objects;               // the leaf objects (spheres, meshes) in the order they are met
     int root_kind = RT_ROOT_BVH;
+    // how the leaf objects nest: the calls that rebuild the world's tree through the C ABI
+    struct Step { enum Kind { OBJECT, BEGIN_GROUP, END_GROUP } kind; size_t object; int group_kind; int axis; };
+    std::vector<Step> steps;
 };
-// Throws std::runtime_error for what the ABI cannot express (nested containers, transforms).
+// Throws std::runtime_error for what the ABI cannot express (an object without a material, ...).
 SceneDescription describe(const World& world);
 
 // a failed rt_* call inside the host layer: carries the call's rt_status and message

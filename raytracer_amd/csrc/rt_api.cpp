@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <chrono>
 #include <string>
@@ -25,6 +26,8 @@ namespace {
 
 thread_local std::string g_last_error;
 std::atomic<int> g_default_build{RT_BUILD_REFERENCE};   // rt_set_default_build
+std::mutex g_cache_dir_lock;
+std::string g_default_cache_dir;                        // rt_set_default_cache_dir
 
 int fail(int code, const std::string& msg) {
     g_last_error = msg;
@@ -129,6 +132,8 @@ struct rt_scene {
     rt_context* ctx = nullptr;
     std::vector<rt_material> mats;
     std::vector<SceneObject> objects;
+    std::vector<SceneGroup> groups{SceneGroup{}};      // [0]: the top level
+    std::vector<size_t> open_groups{0};                // rt_scene_begin_group nesting
     int root_kind = RT_ROOT_BVH;
     int build_mode = RT_BUILD_REFERENCE;
     int traversal = RT_TRAVERSAL_AUTO;
@@ -137,8 +142,10 @@ struct rt_scene {
     uint32_t env_prim_wait = 0;         // RT_PRIM_WAIT, 0 when unset
     uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
     bool committed = false;
+    std::string cache_dir;              // rt_scene_set_cache_dir; empty: the scene is always built
+    int cache_state = RT_CACHE_OFF;
     FlatScene flat;
-    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats;
+    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats, d_xforms;
     DevScene dev{};
     std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
 };
@@ -314,6 +321,10 @@ int rt_scene_create(rt_context* ctx, rt_scene** out) {
     *out = new rt_scene();
     (*out)->ctx = ctx;
     (*out)->build_mode = g_default_build.load();
+    {
+        std::lock_guard<std::mutex> guard(g_cache_dir_lock);
+        (*out)->cache_dir = g_default_cache_dir;
+    }
     if (ctx) ctx->refs.fetch_add(1);
     return RT_OK;
     RT_GUARD_END("rt_scene_create")
@@ -350,6 +361,7 @@ int rt_scene_add_spheres(rt_scene* s, const rt_sphere* sp, size_t n) {
         SceneObject o;
         o.is_mesh = false;
         o.sphere = sp[i];
+        s->groups[s->open_groups.back()].items.push_back((long)s->objects.size());
         s->objects.push_back(std::move(o));
     }
     return RT_OK;
@@ -360,17 +372,48 @@ int rt_scene_add_mesh(rt_scene* s, const rt_triangle* tris, size_t n, const floa
     RT_GUARD_BEGIN
     if (!s || (!tris && n)) return fail(RT_ERR_INVALID, "rt_scene_add_mesh: NULL argument");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-    if (xform) {
-        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-        if (std::memcmp(xform, ident, sizeof(ident)) != 0)
-            return fail(RT_ERR_UNSUPPORTED, "rt_scene_add_mesh: only the identity transform is supported");
-    }
     SceneObject o;
     o.is_mesh = true;
+    if (xform) {
+        static const float ident[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        if (std::memcmp(xform, ident, sizeof(ident)) != 0) {
+            for (int k = 0; k < 16; k++)
+                if (!(xform[k] == xform[k]) || xform[k] - xform[k] != 0.0f)
+                    return fail(RT_ERR_INVALID, "rt_scene_add_mesh: the transform holds a NaN or an infinity");
+            o.has_xform = true;
+            std::memcpy(o.xform, xform, sizeof(o.xform));
+        }
+    }
     o.tris.assign(tris, tris + n);
+    s->groups[s->open_groups.back()].items.push_back((long)s->objects.size());
     s->objects.push_back(std::move(o));
     return RT_OK;
     RT_GUARD_END("rt_scene_add_mesh")
+}
+
+int rt_scene_begin_group(rt_scene* s, int kind, int axis) {
+    RT_GUARD_BEGIN
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_begin_group: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (kind != RT_ROOT_BVH && kind != RT_ROOT_LIST) return fail(RT_ERR_INVALID, "rt_scene_begin_group: the container is RT_ROOT_BVH or RT_ROOT_LIST");
+    if (axis < 0 || axis > 2) return fail(RT_ERR_INVALID, "rt_scene_begin_group: axis must be 0, 1 or 2");
+    if (s->open_groups.size() >= 64) return fail(RT_ERR_UNSUPPORTED, "rt_scene_begin_group: containers nested deeper than 64");
+    SceneGroup g;
+    g.kind = kind;
+    g.axis = axis;
+    s->groups.push_back(std::move(g));
+    s->groups[s->open_groups.back()].items.push_back(-1 - (long)(s->groups.size() - 1));
+    s->open_groups.push_back(s->groups.size() - 1);
+    return RT_OK;
+    RT_GUARD_END("rt_scene_begin_group")
+}
+
+int rt_scene_end_group(rt_scene* s) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_end_group: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    if (s->open_groups.size() < 2) return fail(RT_ERR_STATE, "rt_scene_end_group without rt_scene_begin_group");
+    s->open_groups.pop_back();
+    return RT_OK;
 }
 
 int rt_scene_set_root(rt_scene* s, int root_kind) {
@@ -383,6 +426,8 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
 
 // the kernel form a committed scene is traced with
 static int apply_traversal(rt_scene* s, int mode) {
+    if (s->dev.n_xforms != 0 && mode != RT_TRAVERSAL_AUTO && mode != RT_TRAVERSAL_PER_LANE)
+        return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
     if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
     if (mode == RT_TRAVERSAL_OCTANT) {
@@ -418,6 +463,12 @@ static int apply_traversal(rt_scene* s, int mode) {
     s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
+    if (s->dev.n_xforms != 0) {                // one form follows the transform markers: the plain walk from memory
+        s->dev.sweep = 0;
+        s->dev.refill = 0;
+        s->dev.lds_walk = 0;
+        s->auto_tuned = true;
+    }
     return RT_OK;
 }
 
@@ -434,6 +485,25 @@ int rt_scene_set_build(rt_scene* s, int build_mode) {
     s->build_mode = build_mode;
     return RT_OK;
 }
+
+int rt_set_default_cache_dir(const char* dir) {
+    RT_GUARD_BEGIN
+    std::lock_guard<std::mutex> guard(g_cache_dir_lock);
+    g_default_cache_dir = dir ? dir : "";
+    return RT_OK;
+    RT_GUARD_END("rt_set_default_cache_dir")
+}
+
+int rt_scene_set_cache_dir(rt_scene* s, const char* dir) {
+    RT_GUARD_BEGIN
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_cache_dir: NULL scene");
+    if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
+    s->cache_dir = dir ? dir : "";
+    return RT_OK;
+    RT_GUARD_END("rt_scene_set_cache_dir")
+}
+
+int rt_scene_cache_state(const rt_scene* s) { return s ? s->cache_state : RT_CACHE_OFF; }
 
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     RT_GUARD_BEGIN
@@ -484,6 +554,7 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
     HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
+    HIP_TRY(upload(s->d_xforms, f.xforms.data(), f.xforms.size() * 4));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     s->dev.entries = s->d_entries.p;
     s->dev.units = s->d_units.p;
@@ -491,6 +562,8 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
     s->dev.materials = s->d_mats.p;
+    s->dev.xforms = s->d_xforms.p;
+    s->dev.n_xforms = (uint32_t)(f.xforms.size() / 32);
     s->dev.n_mats = (uint32_t)(f.materials.size() / 8);
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
@@ -503,8 +576,27 @@ int rt_scene_commit(rt_scene* s) {
     RT_GUARD_BEGIN
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-    std::string err = build_flat_scene(s->mats, s->objects, s->root_kind, s->build_mode, s->flat);
-    if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
+    if (s->open_groups.size() != 1) return fail(RT_ERR_STATE, "rt_scene_commit: a container opened with rt_scene_begin_group is not closed");
+    // with a cache directory: the flattened arrays come from the file of this description's key when
+    // there is one (and it is complete); otherwise they are built and the file is written for next time
+    std::string cache_path;
+    uint64_t cache_key = 0;
+    bool loaded = false;
+    s->cache_state = RT_CACHE_OFF;
+    if (!s->cache_dir.empty()) {
+        cache_key = scene_cache_key(s->mats, s->objects, s->groups, s->root_kind, s->build_mode);
+        char name[40];
+        std::snprintf(name, sizeof(name), "/%016llx.rtscene", (unsigned long long)cache_key);
+        cache_path = s->cache_dir + name;
+        loaded = scene_cache_load(cache_path, cache_key, s->flat);
+        if (loaded) s->cache_state = RT_CACHE_LOADED;
+    }
+    if (!loaded) {
+        std::string err = build_flat_scene(s->mats, s->objects, s->groups, s->root_kind, s->build_mode, s->flat);
+        if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
+        if (!cache_path.empty())
+            s->cache_state = scene_cache_store(cache_path, cache_key, s->flat) ? RT_CACHE_STORED : RT_CACHE_STORE_FAILED;
+    }
     rt_context* ctx = s->ctx;
     s->dev.n_entries = (uint32_t)s->flat.n_entries();
     s->dev.n_prims = (uint32_t)s->flat.n_prims();

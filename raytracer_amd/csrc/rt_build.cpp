@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -40,11 +41,59 @@ inline Box surrounding(const Box& a, const Box& b) { // math.rs:167-172 (self = 
 }
 inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+// glam 0.8.7 Mat4 (column-major; m[4 * column + row]) as Mesh uses it (shape.rs:241-251).
+// transform_point3 / transform_vector3 = mul_vec4 of (v, 1) / (v, 0), truncated, and mul_vec4 =
+// ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w in rounded f32 steps; inverse() is the
+// cofactor expansion the crate ports from GLM.  (Restated from the crate's published source; the
+// reference holds nothing that could confirm the operation order.)
+inline void mat4_mul_vec(const float* m, const float v[3], float w, float out[3]) {
+    for (int k = 0; k < 3; k++) {
+        float acc = m[k] * v[0];
+        acc = m[4 + k] * v[1] + acc;
+        acc = m[8 + k] * v[2] + acc;
+        acc = m[12 + k] * w + acc;
+        out[k] = acc;
+    }
+}
+void mat4_inverse(const float* m, float* out) {
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m03 = m[3];
+    const float m10 = m[4], m11 = m[5], m12 = m[6], m13 = m[7];
+    const float m20 = m[8], m21 = m[9], m22 = m[10], m23 = m[11];
+    const float m30 = m[12], m31 = m[13], m32 = m[14], m33 = m[15];
+    const float coef00 = m22 * m33 - m32 * m23, coef02 = m12 * m33 - m32 * m13, coef03 = m12 * m23 - m22 * m13;
+    const float coef04 = m21 * m33 - m31 * m23, coef06 = m11 * m33 - m31 * m13, coef07 = m11 * m23 - m21 * m13;
+    const float coef08 = m21 * m32 - m31 * m22, coef10 = m11 * m32 - m31 * m12, coef11 = m11 * m22 - m21 * m12;
+    const float coef12 = m20 * m33 - m30 * m23, coef14 = m10 * m33 - m30 * m13, coef15 = m10 * m23 - m20 * m13;
+    const float coef16 = m20 * m32 - m30 * m22, coef18 = m10 * m32 - m30 * m12, coef19 = m10 * m22 - m20 * m12;
+    const float coef20 = m20 * m31 - m30 * m21, coef22 = m10 * m31 - m30 * m11, coef23 = m10 * m21 - m20 * m11;
+    const float fac0[4] = {coef00, coef00, coef02, coef03}, fac1[4] = {coef04, coef04, coef06, coef07};
+    const float fac2[4] = {coef08, coef08, coef10, coef11}, fac3[4] = {coef12, coef12, coef14, coef15};
+    const float fac4[4] = {coef16, coef16, coef18, coef19}, fac5[4] = {coef20, coef20, coef22, coef23};
+    const float vec0[4] = {m10, m00, m00, m00}, vec1[4] = {m11, m01, m01, m01};
+    const float vec2[4] = {m12, m02, m02, m02}, vec3[4] = {m13, m03, m03, m03};
+    const float sign_a[4] = {1.0f, -1.0f, 1.0f, -1.0f}, sign_b[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+    float inv[4][4];
+    for (int k = 0; k < 4; k++) {
+        inv[0][k] = ((vec1[k] * fac0[k] - vec2[k] * fac1[k]) + vec3[k] * fac2[k]) * sign_a[k];
+        inv[1][k] = ((vec0[k] * fac0[k] - vec2[k] * fac3[k]) + vec3[k] * fac4[k]) * sign_b[k];
+        inv[2][k] = ((vec0[k] * fac1[k] - vec1[k] * fac3[k]) + vec3[k] * fac5[k]) * sign_a[k];
+        inv[3][k] = ((vec0[k] * fac2[k] - vec1[k] * fac4[k]) + vec2[k] * fac5[k]) * sign_b[k];
+    }
+    const float d0 = m00 * inv[0][0], d1 = m01 * inv[1][0], d2 = m02 * inv[2][0], d3 = m03 * inv[3][0];
+    const float det = (d0 + d1) + (d2 + d3);
+    const float rcp = 1.0f / det;
+    for (int c = 0; c < 4; c++)
+        for (int k = 0; k < 4; k++) out[4 * c + k] = inv[c][k] * rcp;
+}
+
 struct Builder {
     const std::vector<rt_material>& mats;
     std::vector<SceneObject>& objects;
     FlatScene& out;
     std::vector<Box> obj_box;                  // Hittable::get_aabb() per object
+    const std::vector<SceneGroup>* groups = nullptr;
+    std::vector<Box> group_box;                // get_aabb() of every container
+    std::vector<uint32_t> xform_of;            // per object: index of its transform + 1, 0 for none
     // scratch for the mesh currently being emitted
     const SceneObject* mesh = nullptr;
     std::vector<float> tri_min;                // Triangle::get_aabb().min per triangle (3 floats)
@@ -234,9 +283,24 @@ struct Builder {
         }
     }
 
+    // the markers around the tree of a transformed mesh (rt_internal.hpp: END_CODE_*)
+    void push_marker(uint32_t code, uint32_t xform_index) {
+        float* e = entry(push_entry());
+        e[0] = u2f(code); e[1] = u2f(xform_index);
+        e[3] = u2f(TAG_END << TAG_SHIFT);
+    }
     void emit_object(uint32_t oi) {
         const SceneObject& o = objects[oi];
         if (!o.is_mesh) { push_sphere(o); return; }
+        if (xform_of[oi]) {                    // Mesh::hit: ray.transform(&inverse_transform), shape.rs:454
+            push_marker(END_CODE_ENTER, xform_of[oi] - 1);
+            emit_mesh(o);
+            push_marker(END_CODE_LEAVE, xform_of[oi] - 1);
+            return;
+        }
+        emit_mesh(o);
+    }
+    void emit_mesh(const SceneObject& o) {
         mesh = &o;
         size_t n = o.tris.size();
         tri_min.resize(n * 3);
@@ -264,43 +328,73 @@ struct Builder {
         mesh = nullptr;
     }
 
-    // Bvh::new (shape.rs:94-138) on ids[0..n); returns the node's aabb
-    Box emit_bvh(uint32_t* ids, size_t n, int axis) {
+    // An item is an object (>= 0) or a container (< 0: groups[-1 - item]).
+    const Box& item_box(long item) const { return item >= 0 ? obj_box[(size_t)item] : group_box[(size_t)(-1 - item)]; }
+    void emit_item(long item) {
+        if (item >= 0) { emit_object((uint32_t)item); return; }
+        const SceneGroup& g = (*groups)[(size_t)(-1 - item)];
+        if (g.kind == RT_ROOT_LIST) {          // HittableList::hit (shape.rs:60-74): no box of its own
+            for (long c : g.items) emit_item(c);
+        } else {
+            std::vector<long> ids(g.items);
+            emit_bvh(ids.data(), ids.size(), g.axis, false);
+        }
+    }
+    // Bvh::new (shape.rs:94-138) on ids[0..n); returns the node's aabb.  dry: only the box (what
+    // get_aabb() of a container inside another Bvh answers), nothing is emitted.
+    Box emit_bvh(long* ids, size_t n, int axis, bool dry) {
         if (n == 0) {
             Box z{{0, 0, 0}, {0, 0, 0}};
-            close_box(push_box(z));
+            if (!dry) close_box(push_box(z));
             return z;
         }
         if (n == 1) {
-            Box b = obj_box[ids[0]];
+            Box b = item_box(ids[0]);
+            if (dry) return b;
             size_t bx = push_box(b);
-            emit_object(ids[0]);
+            emit_item(ids[0]);
             close_box(bx);
             return b;
         }
         if (n == 2) {
-            uint32_t left = ids[1], right = ids[0];    // pop(), pop()
-            Box b = surrounding(obj_box[left], obj_box[right]);
+            long left = ids[1], right = ids[0];        // pop(), pop()
+            Box b = surrounding(item_box(left), item_box(right));
+            if (dry) return b;
             size_t bx = push_box(b);
-            emit_object(left);
-            emit_object(right);
+            emit_item(left);
+            emit_item(right);
             close_box(bx);
             return b;
         }
-        const std::vector<Box>& ob = obj_box;
-        std::stable_sort(ids, ids + n, [&ob, axis](uint32_t a, uint32_t b) {
-            return ob[a].lo[axis] < ob[b].lo[axis];
+        std::stable_sort(ids, ids + n, [this, axis](long a, long b) {
+            return item_box(a).lo[axis] < item_box(b).lo[axis];
         });
         size_t half = n / 2;
-        size_t bx = push_box(Box{});           // box is known only after both children exist
-        Box l = emit_bvh(ids, half, (axis + 1) % 3);
-        Box r = emit_bvh(ids + half, n - half, (axis + 1) % 3);
+        size_t bx = dry ? 0 : push_box(Box{});  // box is known only after both children exist
+        Box l = emit_bvh(ids, half, (axis + 1) % 3, dry);
+        Box r = emit_bvh(ids + half, n - half, (axis + 1) % 3, dry);
         Box b = surrounding(l, r);
+        if (dry) return b;
         float* e = entry(bx);
         e[0] = b.lo[0]; e[1] = b.lo[1]; e[2] = b.lo[2];
         e[4] = b.hi[0]; e[5] = b.hi[1]; e[6] = b.hi[2];
         close_box(bx);
         return b;
+    }
+    // get_aabb() of every container, innermost first (a container's index is above its parent's)
+    void compute_group_boxes() {
+        group_box.assign(groups->size(), box_infinity());
+        for (size_t g = groups->size(); g-- > 1;) {
+            const SceneGroup& gr = (*groups)[g];
+            if (gr.kind == RT_ROOT_LIST) {     // shape.rs:76-85: fold of obj.get_aabb().surrounding(&acc)
+                Box acc = box_infinity();
+                for (long c : gr.items) acc = surrounding(item_box(c), acc);
+                group_box[g] = acc;
+            } else {
+                std::vector<long> ids(gr.items);
+                group_box[g] = emit_bvh(ids.data(), ids.size(), gr.axis, true);
+            }
+        }
     }
 };
 
@@ -320,6 +414,7 @@ void annotate_children(FlatScene& out) {
         for (int k = 0; k < 3; k++) {
             if (tag == TAG_BOX) c[k] = e[k] + e[4 + k];
             else if (tag == TAG_SPH) c[k] = 2.0f * e[k];
+            else if (tag == TAG_END) c[k] = 0.0f;          // a marker around a transformed mesh: no bounds
             else {
                 const float p1 = e[k] + e[4 + k], p2 = e[k] + e[8 + k];
                 c[k] = std::min(e[k], std::min(p1, p2)) + std::max(e[k], std::max(p1, p2));
@@ -546,8 +641,117 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
     for (std::thread& w : workers) w.join();
 }
 
+// ---------------------------------------------------------------------------------------------
+// scene cache
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct LayoutParams { uint32_t top_budget, pair_align, preorder; };
+LayoutParams layout_params() {                 // experiments: RT_LAYOUT_TOP / RT_LAYOUT_ALIGN (units), RT_LAYOUT_PREORDER
+    LayoutParams p{2048, 4, 0};
+    if (const char* e = std::getenv("RT_LAYOUT_TOP")) p.top_budget = (uint32_t)std::max(0l, std::atol(e));
+    if (const char* e = std::getenv("RT_LAYOUT_ALIGN")) p.pair_align = (uint32_t)std::max(1l, std::atol(e));
+    if (std::getenv("RT_LAYOUT_PREORDER")) p.preorder = 1;
+    return p;
+}
+// 64-bit hash of a byte range, eight bytes at a time (multiply-xorshift mixing); not cryptographic:
+// it only has to tell scenes apart
+uint64_t hash_bytes(uint64_t h, const void* data, size_t n) {
+    const unsigned char* p = (const unsigned char*)data;
+    auto mix = [](uint64_t x) { x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; return x ^ (x >> 32); };
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = mix(h ^ w) + 0x9E3779B97F4A7C15ull;
+    }
+    uint64_t tail = 0;
+    std::memcpy(&tail, p + i, n - i);
+    return mix(h ^ tail ^ ((uint64_t)n << 56));
+}
+constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '2'};
+struct CacheHeader {
+    char magic[8];
+    uint64_t key;
+    uint64_t n_entries_f, n_units_f, n_walk_f, n_geo_f, n_meta, n_mat_f, n_xform_f;   // element counts of the arrays
+    uint32_t kinds_present, has_spheres, depth, ordered_ok, walk_top_units, reserved;
+};
+}  // namespace
+
+uint64_t scene_cache_key(const std::vector<rt_material>& mats, const std::vector<SceneObject>& objects,
+                         const std::vector<SceneGroup>& groups, int root_kind, int build_mode) {
+    uint64_t h = 0x5254414D44ull;
+    const LayoutParams lp = layout_params();
+    const uint32_t head[8] = {(uint32_t)root_kind, (uint32_t)build_mode, lp.top_budget, lp.pair_align, lp.preorder,
+                              ENTRY_FLOATS, UNITS_END, (uint32_t)mats.size()};
+    h = hash_bytes(h, head, sizeof(head));
+    if (!mats.empty()) h = hash_bytes(h, mats.data(), mats.size() * sizeof(rt_material));
+    for (const SceneObject& o : objects) {
+        const uint32_t kind[2] = {o.is_mesh ? 1u : 0u, o.has_xform ? 1u : 0u};
+        h = hash_bytes(h, kind, sizeof(kind));
+        if (!o.is_mesh) h = hash_bytes(h, &o.sphere, sizeof(o.sphere));
+        else if (!o.tris.empty()) h = hash_bytes(h, o.tris.data(), o.tris.size() * sizeof(rt_triangle));
+        if (o.has_xform) h = hash_bytes(h, o.xform, sizeof(o.xform));
+    }
+    for (const SceneGroup& g : groups) {
+        const int32_t gk[2] = {g.kind, g.axis};
+        h = hash_bytes(h, gk, sizeof(gk));
+        if (!g.items.empty()) h = hash_bytes(h, g.items.data(), g.items.size() * sizeof(long));
+    }
+    return h;
+}
+
+bool scene_cache_load(const std::string& path, uint64_t key, FlatScene& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader hd;
+    bool ok = std::fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, CACHE_MAGIC, 8) == 0 && hd.key == key;
+    FlatScene fs;
+    auto rd = [&](auto& vec, uint64_t n) {
+        if (!ok) return;
+        if (n > ((uint64_t)1 << 36)) { ok = false; return; }
+        vec.resize((size_t)n);
+        if (n && std::fread(vec.data(), sizeof(vec[0]), (size_t)n, f) != (size_t)n) ok = false;
+    };
+    rd(fs.entries, hd.n_entries_f); rd(fs.units, hd.n_units_f); rd(fs.walk, hd.n_walk_f); rd(fs.prim_geo, hd.n_geo_f);
+    rd(fs.prim_meta, hd.n_meta); rd(fs.materials, hd.n_mat_f); rd(fs.xforms, hd.n_xform_f);
+    if (ok) {
+        uint64_t tail = 0;                     // the key once more behind the arrays: a complete file
+        ok = std::fread(&tail, 8, 1, f) == 1 && tail == key;
+    }
+    std::fclose(f);
+    if (!ok || fs.units.size() < UNITS_END * 4 || fs.walk.size() < UNITS_END * 4) return false;
+    fs.kinds_present = hd.kinds_present; fs.has_spheres = hd.has_spheres != 0; fs.depth = hd.depth;
+    fs.ordered_ok = hd.ordered_ok != 0; fs.walk_top_units = hd.walk_top_units;
+    out = std::move(fs);
+    return true;
+}
+
+bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& fl) {
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long long)(uintptr_t)&fl) + "_" + std::to_string((long)std::rand());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    CacheHeader hd{};
+    std::memcpy(hd.magic, CACHE_MAGIC, 8);
+    hd.key = key;
+    hd.n_entries_f = fl.entries.size(); hd.n_units_f = fl.units.size(); hd.n_walk_f = fl.walk.size();
+    hd.n_geo_f = fl.prim_geo.size(); hd.n_meta = fl.prim_meta.size(); hd.n_mat_f = fl.materials.size();
+    hd.n_xform_f = fl.xforms.size();
+    hd.kinds_present = fl.kinds_present; hd.has_spheres = fl.has_spheres ? 1u : 0u; hd.depth = fl.depth;
+    hd.ordered_ok = fl.ordered_ok ? 1u : 0u; hd.walk_top_units = fl.walk_top_units;
+    bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
+    auto wr = [&](const auto& vec) {
+        if (ok && !vec.empty()) ok = std::fwrite(vec.data(), sizeof(vec[0]), vec.size(), f) == vec.size();
+    };
+    wr(fl.entries); wr(fl.units); wr(fl.walk); wr(fl.prim_geo); wr(fl.prim_meta); wr(fl.materials); wr(fl.xforms);
+    ok = ok && std::fwrite(&key, 8, 1, f) == 1;
+    ok = std::fclose(f) == 0 && ok;
+    if (ok) ok = std::rename(tmp.c_str(), path.c_str()) == 0;
+    if (!ok) std::remove(tmp.c_str());
+    return ok;
+}
+
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             int root_kind, int build_mode, FlatScene& out) {
+                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out) {
     out = FlatScene();
     if (mats.empty()) return "no materials set";
     if (mats.size() > MAT_MASK) return "too many materials";
@@ -566,6 +770,9 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     out.prim_geo.resize(prim * 4, 0.0f);
     out.prim_meta.resize(prim, 0);
     b.obj_box.resize(objects.size());
+    b.xform_of.assign(objects.size(), 0u);
+    b.groups = &groups;
+    if (groups.empty()) return "internal error: no top-level group";
     for (size_t oi = 0; oi < objects.size(); oi++) {
         SceneObject& o = objects[oi];
         if (!o.is_mesh) {
@@ -579,15 +786,32 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
             for (int k = 0; k < 3; k++) { bx.lo[k] = o.sphere.c[k] - o.sphere.r; bx.hi[k] = o.sphere.c[k] + o.sphere.r; }
             b.obj_box[oi] = bx;
         } else {
-            Box bx = box_infinity();           // Mesh.aabb: unpadded, shape.rs:241-245
+            if (o.has_xform) {                 // Mesh.transform / inverse_transform, shape.rs:212-213, 250
+                b.xform_of[oi] = (uint32_t)(out.xforms.size() / 32) + 1u;
+                out.xforms.resize(out.xforms.size() + 32);
+                float* x = &out.xforms[out.xforms.size() - 32];
+                std::memcpy(x, o.xform, 64);
+                mat4_inverse(o.xform, x + 16);
+            }
+            Box bx = box_infinity();           // Mesh.aabb: unpadded, of the transformed vertices, shape.rs:241-245
             for (size_t i = 0; i < o.tris.size(); i++) {
                 const rt_triangle& t = o.tris[i];
                 if (t.mat >= mats.size()) return "triangle material index out of range";
-                grow_point(bx, t.p[0]); grow_point(bx, t.p[1]); grow_point(bx, t.p[2]);
-                // shape.rs:306: normalize(+-v1.n) = +-(v1.n / |v1.n|); glam: v / sqrt((x*x+y*y)+z*z)
-                float len = std::sqrt((t.n0[0] * t.n0[0] + t.n0[1] * t.n0[1]) + t.n0[2] * t.n0[2]);
                 float* g = &out.prim_geo[((size_t)o.prim_base + i) * 4];
-                g[0] = t.n0[0] / len; g[1] = t.n0[1] / len; g[2] = t.n0[2] / len; g[3] = 0.0f;
+                if (o.has_xform) {
+                    for (int k = 0; k < 3; k++) {
+                        float p[3];
+                        mat4_mul_vec(o.xform, t.p[k], 1.0f, p);
+                        grow_point(bx, p);
+                    }
+                    // the normal goes through the transform at every hit (shape.rs:303-307): keep it raw
+                    g[0] = t.n0[0]; g[1] = t.n0[1]; g[2] = t.n0[2]; g[3] = u2f(b.xform_of[oi]);
+                } else {
+                    grow_point(bx, t.p[0]); grow_point(bx, t.p[1]); grow_point(bx, t.p[2]);
+                    // shape.rs:306: normalize(+-v1.n) = +-(v1.n / |v1.n|); glam: v / sqrt((x*x+y*y)+z*z)
+                    float len = std::sqrt((t.n0[0] * t.n0[0] + t.n0[1] * t.n0[1]) + t.n0[2] * t.n0[2]);
+                    g[0] = t.n0[0] / len; g[1] = t.n0[1] / len; g[2] = t.n0[2] / len; g[3] = 0.0f;
+                }
                 out.prim_meta[o.prim_base + i] = b.matkind(t.mat);
                 out.kinds_present |= 1u << mats[t.mat].kind;
             }
@@ -601,26 +825,31 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
         m[4] = u2f(mats[i].kind); m[5] = u2f(mats[i].flags);
     }
 
-    std::vector<uint32_t> ids(objects.size());
-    std::iota(ids.begin(), ids.end(), 0u);
+    for (const SceneGroup& g : groups) {
+        if (g.kind != RT_ROOT_BVH && g.kind != RT_ROOT_LIST) return "unknown container kind";
+        if (g.axis < 0 || g.axis > 2) return "Bvh axis must be 0, 1 or 2";
+        for (long it : g.items)
+            if (it >= (long)objects.size() || -1 - it >= (long)groups.size()) return "internal error: bad container item";
+    }
+    b.compute_group_boxes();
+    std::vector<long> ids(groups[0].items);    // the children of World.hittable
     if (root_kind == RT_ROOT_SINGLE) {
-        if (objects.size() != 1) return "RT_ROOT_SINGLE needs exactly one object";
-        b.emit_object(0);
+        if (ids.size() != 1) return "RT_ROOT_SINGLE needs exactly one object";
+        b.emit_item(ids[0]);
     } else if (root_kind == RT_ROOT_LIST) {
         // HittableList::hit (shape.rs:60-74): every object in order, t_max = closest so far
-        for (uint32_t oi : ids) b.emit_object(oi);
+        for (long it : ids) b.emit_item(it);
     } else if (root_kind == RT_ROOT_BVH) {
-        b.emit_bvh(ids.data(), ids.size(), 0);
+        b.emit_bvh(ids.data(), ids.size(), 0, false);
     } else {
         return "unknown root kind";
     }
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
     annotate_children(out);
     if (!pack_units(out)) return "scene too large for 30-bit unit links";
-    uint32_t top_budget = 2048, pair_align = 4;            // experiments: RT_LAYOUT_TOP / RT_LAYOUT_ALIGN (units)
-    if (const char* e = std::getenv("RT_LAYOUT_TOP")) top_budget = (uint32_t)std::max(0l, std::atol(e));
-    if (const char* e = std::getenv("RT_LAYOUT_ALIGN")) pair_align = (uint32_t)std::max(1l, std::atol(e));
-    if (!pack_walk_units(out, top_budget, pair_align)) return "scene too large for 30-bit unit links";
+    const LayoutParams lp = layout_params();
+    if (!pack_walk_units(out, lp.top_budget, lp.pair_align)) return "scene too large for 30-bit unit links";
+    if (!out.xforms.empty()) out.ordered_ok = false;       // the near-first walks do not follow the transform markers
     return std::string();
 }
 

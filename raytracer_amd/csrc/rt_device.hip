@@ -89,16 +89,21 @@ __device__ __forceinline__ void lane_ray_init(LaneRay& r, float ox, float oy, fl
 }
 
 // math.rs:149-165 on the box held in (a, b); returns the ray's next cursor.
-// `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does fmaxf (likewise fminf); the
-// sign of a zero cannot change `t_max <= t_min`; and the per-axis early return equals the one
-// test after the third axis because t_min only grows and t_max only shrinks.
+// `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does fmaxf (likewise fminf over the
+// three t1); the sign of a zero cannot change `t_max <= t_min`; and the per-axis early return
+// equals the one test after the third axis because t_min only grows and t_max only shrinks.
+// The narrowed t_max itself can be a NaN (the reference accepts a sphere hit whose discriminant
+// overflowed, shape.rs:25-36, and hands its NaN t on as t_max): `t1 < t_max ? t1 : t_max` then
+// keeps the NaN through all three axes and `t_max <= t_min` is false, i.e. every later box is
+// entered.  near_or() is that select form for the last step, so a NaN best_t stays a NaN.
+__device__ __forceinline__ float near_or(float far3, float best_t) { return far3 < best_t ? far3 : best_t; }
 __device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, const LaneRay& r, float t_min) {
     const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;       // math.rs:155
     const float x0 = (a.x - r.ox) * r.ix, x1 = (b.x - r.ox) * r.ix;
     const float y0 = (a.y - r.oy) * r.iy, y1 = (b.y - r.oy) * r.iy;
     const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
     const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
-    const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
+    const float tmx = near_or(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
     return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : f2u(b.w);            // missed: the skip link; hit: the first child
 }
 
@@ -269,6 +274,83 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     best_prim = r.best_prim;
 }
 
+// glam's Mat4::transform_point3 (w = 1) / transform_vector3 (w = 0) on the four columns at m:
+// ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w in rounded f32 steps (no contraction here).
+__device__ __forceinline__ void xf_apply(const float4* __restrict__ m, float x, float y, float z, float w, float& ox,
+                                         float& oy, float& oz) {
+    const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+    ox = c3.x * w + (c2.x * z + (c1.x * y + c0.x * x));
+    oy = c3.y * w + (c2.y * z + (c1.y * y + c0.y * x));
+    oz = c3.z * w + (c2.z * z + (c1.z * y + c0.z * x));
+}
+
+// What shading sees of a hit on a triangle of a TRANSFORMED mesh (shape.rs:298-307): the point is
+// transform * (local ray at t), the normal normalize(transform * (+-v1.n)) as a vector, and the
+// facing test pits the LOCAL ray's direction against that WORLD normal (the reference's `ray`
+// there is the shadowing local one).  g = (raw v1.n, transform index + 1).
+__device__ __forceinline__ void xf_hit(const float4* __restrict__ xforms, const float4& g, bool backface, float ox,
+                                       float oy, float oz, float dx, float dy, float dz, float t, float& px, float& py,
+                                       float& pz, float& nx, float& ny, float& nz, bool& front) {
+    const float4* m = xforms + 8u * (f2u(g.w) - 1u);
+    float lox, loy, loz, ldx, ldy, ldz;
+    xf_apply(m + 4, ox, oy, oz, 1.0f, lox, loy, loz);      // Ray::transform(inverse_transform), camera.rs:137-142
+    xf_apply(m + 4, dx, dy, dz, 0.0f, ldx, ldy, ldz);
+    xf_apply(m, lox + ldx * t, loy + ldy * t, loz + ldz * t, 1.0f, px, py, pz);
+    float wx, wy, wz;
+    xf_apply(m, backface ? -g.x : g.x, backface ? -g.y : g.y, backface ? -g.z : g.z, 0.0f, wx, wy, wz);
+    const float len = sqrtf(dot3(wx, wy, wz, wx, wy, wz));
+    nx = wx / len; ny = wy / len; nz = wz / len;
+    front = dot3(ldx, ldy, ldz, nx, ny, nz) < 0.0f;
+}
+
+// Per-lane walk of a scene that holds transformed meshes: the linked units carry an ENTER marker
+// in front of such a mesh's tree and a LEAVE marker behind it (rt_internal.hpp: END_CODE_*).  At
+// ENTER the lane's ray goes to the mesh's local space, as Mesh::hit does before it descends
+// (shape.rs:454); t is the same parameter in both spaces, so best_t carries over; at LEAVE the
+// caller's ray is back.  Meshes are leaves, so one saved ray is enough.  A plain loop: every lane
+// handles whatever entry it stands at in every trip.
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_xf(const float4* __restrict__ ent, const float4* __restrict__ xforms,
+                                               bool valid, float ox, float oy, float oz, float dx, float dy, float dz,
+                                               float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
+    LaneRay r;
+    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    const float4 ended = make_float4(u2f(END_CODE_END), 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
+    float4 a = ended, b = ended;
+    if (valid) { a = ent[0]; b = ent[1]; }
+    for (;;) {
+        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
+        const bool done = tag == TAG_END && f2u(a.x) == END_CODE_END;
+        if (__ballot(!done) == 0ull) break;
+        if (tag == TAG_BOX) {
+            if (COUNT) cnt.box++;
+            r.i = box_step(a, b, r, t_min);
+        } else if (tag == TAG_TRI) {
+            if (COUNT) cnt.tri++;
+            const float4 c = ent[r.i + 2];
+            tri_step(a, b, c, r, t_min);
+            r.i = f2u(c.w);
+        } else if (tag == TAG_SPH) {
+            if (COUNT) cnt.sph++;
+            sphere_step(a, b, r, t_min);
+            r.i = f2u(b.y);
+        } else if (!done) {
+            if (f2u(a.x) == END_CODE_ENTER) {
+                const float4* inv = xforms + 8u * f2u(a.y) + 4u;
+                xf_apply(inv, ox, oy, oz, 1.0f, r.ox, r.oy, r.oz);
+                xf_apply(inv, dx, dy, dz, 0.0f, r.dx, r.dy, r.dz);
+            } else {
+                r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+            }
+            r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;     // math.rs:152
+            r.i = f2u(b.y);
+        }
+        if (!done) { a = ent[r.i]; b = ent[r.i + 1]; }
+    }
+    best_t = r.best_t;
+    best_prim = r.best_prim;
+}
+
 // math.rs:149-165 as a predicate (the same arithmetic as box_step)
 __device__ __forceinline__ bool box_hit(const float4& a, const float4& b, const LaneRay& r, float t_min) {
     const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
@@ -276,7 +358,7 @@ __device__ __forceinline__ bool box_hit(const float4& a, const float4& b, const 
     const float y0 = (a.y - r.oy) * r.iy, y1 = (b.y - r.oy) * r.iy;
     const float z0 = (a.z - r.oz) * r.iz, z1 = (b.z - r.oz) * r.iz;
     const float tmn = fmaxf(fmaxf(fmaxf(nx ? x1 : x0, ny ? y1 : y0), nz ? z1 : z0), t_min);
-    const float tmx = fminf(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
+    const float tmx = near_or(fminf(fminf(nx ? x0 : x1, ny ? y0 : y1), nz ? z0 : z1), r.best_t);
     return !(tmx <= tmn);
 }
 
@@ -459,17 +541,14 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
         uint32_t np0, np1;
         if (tag == TAG_BOX) {
             if (COUNT) cnt.box += (uint32_t)((on0 >> (threadIdx.x & 63u)) & 1ull) + (uint32_t)((on1 >> (threadIdx.x & 63u)) & 1ull);
-            // math.rs:153-162.  `t0 > t_min ? t0 : t_min` keeps t_min when t0 is NaN and so does
-            // fmaxf (likewise fminf); the sign of a zero cannot change `t_max <= t_min`; and the
-            // per-axis early return equals the one test after the third axis because t_min only
-            // grows and t_max only shrinks.
+            // math.rs:153-162 as in box_step (a NaN best_t stays a NaN: near_or)
             const f32x2 x0 = (E[0] - ox) * ix, x1 = (E[4] - ox) * ix;
             const f32x2 y0 = (E[1] - oy) * iy, y1 = (E[5] - oy) * iy;
             const f32x2 z0 = (E[2] - oz) * iz, z1 = (E[6] - oz) * iz;
             const float tmn0 = fmaxf(fmaxf(fmaxf(nx0 ? x1.x : x0.x, ny0 ? y1.x : y0.x), nz0 ? z1.x : z0.x), t_min);
-            const float tmx0 = fminf(fminf(fminf(nx0 ? x0.x : x1.x, ny0 ? y0.x : y1.x), nz0 ? z0.x : z1.x), bt0);
+            const float tmx0 = near_or(fminf(fminf(nx0 ? x0.x : x1.x, ny0 ? y0.x : y1.x), nz0 ? z0.x : z1.x), bt0);
             const float tmn1 = fmaxf(fmaxf(fmaxf(nx1 ? x1.y : x0.y, ny1 ? y1.y : y0.y), nz1 ? z1.y : z0.y), t_min);
-            const float tmx1 = fminf(fminf(fminf(nx1 ? x0.y : x1.y, ny1 ? y0.y : y1.y), nz1 ? z0.y : z1.y), bt1);
+            const float tmx1 = near_or(fminf(fminf(nx1 ? x0.y : x1.y, ny1 ? y0.y : y1.y), nz1 ? z0.y : z1.y), bt1);
             const uint32_t skip = w & SKIP_MASK;
             nxt0 = tmx0 <= tmn0 ? skip : e + 1u;
             nxt1 = tmx1 <= tmn1 ? skip : e + 1u;
@@ -558,15 +637,19 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
         const uint32_t id = prim & PRIM_ID_MASK;
         const float4 g = geo[id];
         const uint32_t meta = sc.prim_meta[id];
-        const float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
         float nx, ny, nz;
         if (meta & META_SPHERE) {                      // shape.rs:41
-            nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
+            const float sx = ox + dx * t, sy = oy + dy * t, sz = oz + dz * t;
+            nx = (sx - g.x) / g.w; ny = (sy - g.y) / g.w; nz = (sz - g.z) / g.w;
         } else {                                       // shape.rs:298-307
             const bool bf = (prim & PRIM_BACKFACE) != 0;
             nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
         }
-        const bool front = dot3(dx, dy, dz, nx, ny, nz) < 0.0f;   // camera.rs:112-119
+        bool front = dot3(dx, dy, dz, nx, ny, nz) < 0.0f;   // camera.rs:112-119
+        float px = ox + dx * t, py = oy + dy * t, pz = oz + dz * t;   // Ray::at
+        if (sc.n_xforms != 0u && !(meta & META_SPHERE) && f2u(g.w) != 0u)
+            xf_hit((const float4*)sc.xforms, g, (prim & PRIM_BACKFACE) != 0, ox, oy, oz, dx, dy, dz, t, px, py, pz, nx, ny,
+                   nz, front);
         h.t = t; h.prim_id = id;
         h.p[0] = px; h.p[1] = py; h.p[2] = pz;
         h.n[0] = front ? nx : -nx; h.n[1] = front ? ny : -ny; h.n[2] = front ? nz : -nz;
@@ -583,7 +666,7 @@ extern __shared__ uint32_t lds_stack[];
 // SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene),
 //        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
-//        8 = 7 with idle lanes refilled (k_path only)
+//        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -627,6 +710,8 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
                                            valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            else if (SWEEP == 9)
+                closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
@@ -991,6 +1076,8 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                 closest_hit<COUNT>((const float4*)lds_stack, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 9)
+                closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
@@ -1080,7 +1167,7 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
             const uint32_t klo = f2u(b.w), khi = f2u(c.w);
             slot = f2u(a.w);
             // hit point and face-forwarded normal
-            const float px = a.x + b.x * t, py = a.y + b.y * t, pz = a.z + b.z * t;
+            float px = a.x + b.x * t, py = a.y + b.y * t, pz = a.z + b.z * t;
             float nx, ny, nz;
             if (meta & META_SPHERE) {
                 nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
@@ -1088,7 +1175,10 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
                 const bool bf = (h.y & PRIM_BACKFACE) != 0;
                 nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
             }
-            const bool front = dot3(b.x, b.y, b.z, nx, ny, nz) < 0.0f;
+            bool front = dot3(b.x, b.y, b.z, nx, ny, nz) < 0.0f;
+            if (sc.n_xforms != 0u && !(meta & META_SPHERE) && f2u(g.w) != 0u)   // a triangle of a transformed mesh
+                xf_hit((const float4*)sc.xforms, g, (h.y & PRIM_BACKFACE) != 0, a.x, a.y, a.z, b.x, b.y, b.z, t, px, py, pz,
+                       nx, ny, nz, front);
             if (!front) { nx = -nx; ny = -ny; nz = -nz; }
             float ddx, ddy, ddz, ar = m0.x, ag = m0.y, ab = m0.z;
             if (KIND == RT_MAT_LAMBERT) {                  // material.rs:27-56
@@ -1326,7 +1416,7 @@ static inline int check_launch() { return hipGetLastError() == hipSuccess ? 0 : 
 
 // Which unit holds the kernel a scene is traced with: the wave sweep lives in the default unit,
 // every per-lane walk in the unit built without SLP vectorisation.
-static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant; }
+static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant && !sc.n_xforms; }
 int launch_trace_api_walk(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min, float t_max,
                           void* d_hits, Totals* d_counts, bool count, uint32_t grid);
 int launch_trace_walk(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
@@ -1370,7 +1460,8 @@ int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* 
                           float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
-    if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
+    if (sc.n_xforms) { if (count) RT_TRACE_API(true, 9); else RT_TRACE_API(false, 9); }
+    else if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
     else if (sc.ordered) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
     return check_launch();
@@ -1384,7 +1475,8 @@ int launch_trace_walk(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom&
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.octant) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
+    if (sc.n_xforms) { if (count) RT_TRACE(true, 9); else RT_TRACE(false, 9); }
+    else if (sc.octant) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
     else if (sc.ordered) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
     return check_launch();
@@ -1398,6 +1490,7 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
+    if (sc.n_xforms) { RT_PATH(9); return check_launch(); }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
         if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);

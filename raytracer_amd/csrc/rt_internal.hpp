@@ -30,7 +30,13 @@ namespace rtamd {
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ENTRY_FLOATS = 16;
 constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
-constexpr uint32_t TAG_END = 3;   // device copy only: one entry behind the last, where the wave sweep stops
+constexpr uint32_t TAG_END = 3;   // behind the last entry (where every walk stops) ...
+// ... and, in scenes with transformed meshes only, the two markers around such a mesh's tree: the
+// first word of the entry tells them apart (END_CODE_END = 0: the end).  ENTER carries the index of
+// the mesh's transform in its second word: the ray goes to the mesh's local space
+// (Ray::transform(inverse_transform), shape.rs:454); LEAVE restores the caller's ray.  Both are
+// two-unit entries that name the entry behind them like a sphere does.
+constexpr uint32_t END_CODE_END = 0, END_CODE_ENTER = 1, END_CODE_LEAVE = 2;
 constexpr uint32_t TAG_SHIFT = 30;
 constexpr uint32_t SKIP_MASK = (1u << TAG_SHIFT) - 1u;
 // Box entries, fourth float of the second float4 (unused by the reference-order walks): links for
@@ -56,6 +62,10 @@ struct FlatScene {
     std::vector<float> prim_geo;       // 4 floats per primitive: tri (unit n0, 0) / sphere (c, r)
     std::vector<uint32_t> prim_meta;   // material index | material kind << KIND_SHIFT | META_SPHERE
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
+    // 32 floats per transformed mesh: Mesh.transform then Mesh.inverse_transform (shape.rs:212-213),
+    // column-major.  A triangle of such a mesh keeps its raw first-vertex normal in prim_geo and the
+    // transform's index + 1 in the fourth word (0: no transform).
+    std::vector<float> xforms;
     uint32_t kinds_present = 0;        // bit k set when a material of kind k is referenced
     bool has_spheres = false;
     // The same entries packed for the per-lane walks in 16-byte units (one float4 each): a box or a
@@ -86,6 +96,17 @@ struct SceneObject {
     rt_sphere sphere{};
     std::vector<rt_triangle> tris;
     uint32_t prim_base = 0;
+    bool has_xform = false;            // Mesh.transform is not Mat4::identity() bit for bit
+    float xform[16] = {};              // column-major
+};
+
+// A container object (Bvh or HittableList, shape.rs:55-57, 87-91) and its children in order:
+// item >= 0 is objects[item], item < 0 is groups[-1 - item].  groups[0] is the top level, whose
+// kind is the scene's root kind.
+struct SceneGroup {
+    int kind = RT_ROOT_BVH;
+    int axis = 0;                      // Bvh::new(objects, axis)
+    std::vector<long> items;
 };
 
 // Builds the reference-topology trees and flattens them.  Returns an empty string on success,
@@ -93,7 +114,17 @@ struct SceneObject {
 // build_mode RT_BUILD_SAH replaces the reference's median split inside meshes by a binned
 // surface-area-heuristic split (same entry format, same box padding, one triangle per leaf).
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             int root_kind, int build_mode, FlatScene& out);
+                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out);
+
+// Binary scene cache: the flattened arrays of a scene on disk, keyed by what they were built from.
+// scene_cache_key() hashes the description (materials, every sphere and triangle, transforms,
+// containers, root kind) together with the build mode and the layout parameters; the file name is
+// that key, and the file repeats it in its header with the array sizes.  load returns false (and
+// leaves `out` untouched) when the file is absent, truncated or of another key or format version.
+uint64_t scene_cache_key(const std::vector<rt_material>& mats, const std::vector<SceneObject>& objects,
+                         const std::vector<SceneGroup>& groups, int root_kind, int build_mode);
+bool scene_cache_load(const std::string& path, uint64_t key, FlatScene& out);
+bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& flat);   // temp file + rename
 
 // The unit array once per direction octant (bit k of the octant: the ray's direction is negative
 // along axis k), copy o at units [o * (n_units + UNITS_END), ...) with its own end units and links
@@ -127,6 +158,8 @@ struct DevScene {
     uint32_t stack_depth;     // ordered walk: stack slots per lane (the tree's depth)
     uint32_t lds_walk;        // 1: the unit array is small enough to be walked out of LDS
     uint32_t refill;          // per-lane walk in the fused kernel: idle lanes that trigger a refill from the segment (0: off)
+    const void* xforms;       // float4[8 * n_xforms]: transform and inverse of every transformed mesh
+    uint32_t n_xforms;        // > 0: the scene is walked by the form that follows ENTER / LEAVE markers
     const void* units_oct;    // float4[8 * (n_units + UNITS_END)]: the unit array once per direction octant (octant walk)
     uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
 };

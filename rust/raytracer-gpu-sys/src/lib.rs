@@ -21,6 +21,10 @@ pub const RT_TRAVERSAL_ORDERED: c_int = 3;
 pub const RT_TRAVERSAL_OCTANT: c_int = 4;
 pub const RT_BUILD_REFERENCE: c_int = 0;
 pub const RT_BUILD_SAH: c_int = 1;
+pub const RT_CACHE_OFF: c_int = 0;
+pub const RT_CACHE_STORED: c_int = 1;
+pub const RT_CACHE_LOADED: c_int = 2;
+pub const RT_CACHE_STORE_FAILED: c_int = 3;
 pub const RT_RENDER_PROFILE: u32 = 1;
 pub const RT_RENDER_COUNT_VISITS: u32 = 2;
 pub const RT_RENDER_STAGED: u32 = 4;
@@ -85,10 +89,15 @@ extern "C" {
     pub fn rt_scene_set_materials(scene: *mut rt_scene, mats: *const rt_material, n: usize) -> c_int;
     pub fn rt_scene_add_spheres(scene: *mut rt_scene, spheres: *const rt_sphere, n: usize) -> c_int;
     pub fn rt_scene_add_mesh(scene: *mut rt_scene, tris: *const rt_triangle, n: usize, xform: *const f32) -> c_int;
+    pub fn rt_scene_begin_group(scene: *mut rt_scene, kind: c_int, axis: c_int) -> c_int;
+    pub fn rt_scene_end_group(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_set_root(scene: *mut rt_scene, root_kind: c_int) -> c_int;
     pub fn rt_scene_set_traversal(scene: *mut rt_scene, mode: c_int) -> c_int;
     pub fn rt_scene_set_build(scene: *mut rt_scene, mode: c_int) -> c_int;
     pub fn rt_set_default_build(mode: c_int) -> c_int;
+    pub fn rt_set_default_cache_dir(dir: *const c_char) -> c_int;
+    pub fn rt_scene_set_cache_dir(scene: *mut rt_scene, dir: *const c_char) -> c_int;
+    pub fn rt_scene_cache_state(scene: *const rt_scene) -> c_int;
     pub fn rt_scene_commit(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_num_prims(scene: *const rt_scene) -> usize;
     pub fn rt_scene_num_entries(scene: *const rt_scene) -> usize;
@@ -132,6 +141,7 @@ extern "C" {
     pub fn rt_world_object_info(world: *const rt_world, i: usize, count: *mut usize) -> c_int;
     pub fn rt_world_get_sphere(world: *const rt_world, i: usize, out: *mut rt_sphere) -> c_int;
     pub fn rt_world_get_mesh(world: *const rt_world, i: usize, out: *mut rt_triangle) -> c_int;
+    pub fn rt_world_get_mesh_xform(world: *const rt_world, i: usize, out: *mut f32) -> c_int;
     pub fn rt_world_root_kind(world: *const rt_world) -> c_int;
     pub fn rt_world_render(world: *mut rt_world, width: u32, height: u32, spp: u32, max_bounces: u32, seed: u64,
                            accum_rgb: *mut f32, stats: *mut rt_stats) -> c_int;

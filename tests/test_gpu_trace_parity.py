@@ -173,3 +173,29 @@ def test_adversarial_rays(rt, ob, ctx, root):
     rays["o"] = np.abs(rays["o"]) * np.float32([-1.0, -1.0, 1.0])          # inside the room
     want, _ = osc.trace(rays)
     _check_all_modes(rt, sc, rays, want)
+
+
+def test_nan_hit_leaves_every_later_box_open(rt, ob, ctx):
+    """A sphere hit whose discriminant overflowed is accepted with t = NaN (shape.rs:25-36), and that
+    NaN is the t_max of every later test: `t1 < t_max ? t1 : t_max` keeps it and `t_max <= t_min` is
+    false, so the reference enters every box from then on and a later sphere can still replace the
+    hit.  Spheres under boxes (a Bvh inside a HittableList behind loose spheres) make that visible."""
+    mats, _, _ = random_scene(ob, 5)
+    rng = np.random.default_rng(12)
+
+    def spheres(n):
+        sp = np.zeros(n, dtype=ob.sphere_dt)
+        sp["c"] = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+        sp["r"] = rng.uniform(0.3, 1.2, n).astype(np.float32)
+        sp["mat"] = rng.integers(0, 6, n)
+        return sp
+
+    objects = [("spheres", spheres(6)), ("bvh", [("spheres", spheres(40))]), ("spheres", spheres(3))]
+    osc = ob.Scene.from_description(mats, objects, ob.ROOT_LIST)
+    sc = rt.Scene(ctx, mats, objects, ob.ROOT_LIST)
+    rays = random_rays(ob, 8, 100000, -5.0, 5.0)
+    rays["d"] *= np.float32(1e18)
+    want, _ = osc.trace(rays)
+    nan = np.isnan(want["t"])
+    assert nan.sum() > 1000 and (want["prim_id"][nan] >= 6).sum() > 100     # NaN hits replaced by spheres under the boxes
+    _check_all_modes(rt, sc, rays, want)

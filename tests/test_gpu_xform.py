@@ -1,0 +1,73 @@
+"""Transformed meshes (Mesh.transform, shape.rs:236-257, 303-307, 452-456; Ray::transform,
+camera.rs:137-142) and containers inside containers (shape.rs:55-57, 87-138) on the GPU against the
+oracle: primitive id exact, t bit-exact, hit point / normal / facing equal, images within the
+Monte-Carlo bound.  Parity here is GPU <-> oracle: glam's Mat4 arithmetic is restated on both
+sides from the crate's published source, and the reference ships nothing that could pin it."""
+import numpy as np
+import pytest
+
+from helpers import adversarial_rays, asset, assert_hits_equal, mirror, product_camera, random_rays
+from test_gpu_render import _compare
+from test_host_layer import _nested_description
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("root", [0, 2])
+@pytest.mark.parametrize("with_xforms", [False, True])
+def test_nested_and_transformed_hits(rt, ob, ctx, root, with_xforms):
+    mats, objects = _nested_description(ob, 71 + root, with_xforms)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(ctx, mats, objects, root)
+    rays = random_rays(ob, 31, 200_000, -5.0, 5.0)
+    for t_min, t_max in [(0.001, np.inf), (0.05, 2.0)]:
+        want, st = osc.trace(rays, t_min, t_max)
+        assert (want["prim_id"] != ob.MISS).sum() > (15_000 if t_max == np.inf else 1_000)
+        assert_hits_equal(sc.trace(rays, t_min, t_max), want)
+    if with_xforms:
+        for mode in (rt.TRAVERSAL_SWEEP, rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT):
+            with pytest.raises(rt.RtError, match="per-lane walk only"):
+                sc.set_traversal(mode)
+        sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+        assert_hits_equal(sc.trace(rays[:50_000]), osc.trace(rays[:50_000])[0])
+        # counts: the markers are not tests
+        import torch
+        d_rays = torch.from_numpy(rays[:50_000].view(np.float32).reshape(-1, 6)).cuda()
+        d_hits = torch.zeros(50_000 * 10, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        _, st = osc.trace(rays[:50_000])
+        assert sc.trace_device(d_rays.data_ptr(), 50_000, d_hits.data_ptr(), count=True) == \
+            (st["box_tests"], st["tri_tests"], st["sph_tests"])
+    else:
+        from test_gpu_trace_parity import _check_all_modes
+        want, _ = osc.trace(rays)
+        _check_all_modes(rt, sc, rays, want)
+        adv = adversarial_rays(rt, 3, 50_000, 5.0)
+        _check_all_modes(rt, sc, adv, osc.trace(adv)[0])
+
+
+def test_world2_with_translated_planes(rt, ob, ctx):
+    """create_world2 with the two planes the reference keeps in a comment (Mesh::plane with
+    Mat4::from_translation, main.rs:195-204): host constructor == oracle constructor, hits and image."""
+    osc = ob.Scene.world2(asset("thing.obj"), 2)
+    w = rt.World.world2(ctx, variant=2)
+    rays = np.concatenate([osc.record_rays(128, 96, 4, 6, cap=200_000), random_rays(ob, 5, 50_000, -2.0, 2.0)])
+    want, _ = osc.trace(rays)
+    on_planes = np.isin(want["prim_id"], [0, 1, 2, 3])
+    assert on_planes.sum() > 10_000                                    # the planes are the first four primitives
+    assert_hits_equal(w.scene.trace(rays), want)
+    assert_hits_equal(mirror(rt, ctx, osc).trace(rays), want)
+    w.close()
+    _compare(rt, ob, ctx, osc, 96, 96, 48, 6, clip=6.0)
+
+
+def test_transformed_scene_image_and_staged_launches(rt, ob, ctx):
+    mats, objects = _nested_description(ob, 83, True)
+    cam = ((6.0, -7.0, 4.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.05, 9.0)
+    osc = ob.Scene.from_description(mats, objects, 0, camera=cam, sky=0.8)
+    _compare(rt, ob, ctx, osc, 96, 72, 48, 6, clip=6.0)
+    sc = rt.Scene(ctx, mats, objects, 0)
+    pc = product_camera(rt, osc, 96, 72)
+    fused, st = sc.render(pc, rt.Scene.params(96, 72, 16, 6, osc.sky, max_paths=96 * 72 * 5))
+    staged, st2 = sc.render(pc, rt.Scene.params(96, 72, 16, 6, osc.sky, max_paths=96 * 72 * 5, flags=rt.RENDER_STAGED))
+    assert st["rays_traced"] == st2["rays_traced"] and np.array_equal(fused.view(np.uint32), staged.view(np.uint32))

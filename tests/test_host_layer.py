@@ -71,13 +71,15 @@ def test_argument_errors(rt):
 def _resolved(materials, objects):
     """Object list with material indices replaced by the material records they point at."""
     out = []
-    for kind, arr in objects:
+    for item in objects:
+        kind, arr = item[0], item[1]
         geo = b"".join(np.ascontiguousarray(arr[n]).tobytes() for n in arr.dtype.names if n != "mat")
-        out.append((kind, geo, materials[arr["mat"]].tobytes()))
+        xf = np.asarray(item[2], dtype=np.float32).tobytes() if len(item) > 2 else b""
+        out.append((kind, geo, materials[arr["mat"]].tobytes(), xf))
     return out
 
 
-@pytest.mark.parametrize("which", ["world1", "world2", "world2_glass", "cornell", "cornell_plane"])
+@pytest.mark.parametrize("which", ["world1", "world2", "world2_glass", "world2_planes", "cornell", "cornell_plane"])
 def test_scene_constructors_match_oracle(rt, ob, which):
     if which == "world1":
         w, o = rt.World.world1(None), ob.Scene.world1()
@@ -85,6 +87,9 @@ def test_scene_constructors_match_oracle(rt, ob, which):
         w, o = rt.World.world2(None, asset("thing.obj"), 0), ob.Scene.world2(asset("thing.obj"), 0)
     elif which == "world2_glass":
         w, o = rt.World.world2(None, asset("thing.obj"), 1), ob.Scene.world2(asset("thing.obj"), 1)
+    elif which == "world2_planes":             # Mesh::plane + Mat4::from_translation (main.rs:195-204)
+        w, o = rt.World.world2(None, asset("thing.obj"), 2), ob.Scene.world2(asset("thing.obj"), 2)
+        assert [len(it) for it in w.objects()[:3]] == [3, 3, 2] and w.objects()[0][2][14] == np.float32(-0.5)
     elif which == "cornell":
         w, o = rt.World.cornell_box(None, asset("cornell_box.obj")), ob.Scene.cornell_box(asset("cornell_box.obj"))
     else:
@@ -250,11 +255,27 @@ def _prim_test(e, tag, prim, o, d, t_min, best_t, best):
     return best_t, best
 
 
-def _walk(entries, o, d, t_min, t_max):
-    """Pre-order walk with skip links, f32 arithmetic; mirrors the device loop."""
+def _mat_vec(m, v, w):
+    """glam Mat4 * (v, w), truncated: ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w in f32 steps"""
+    out = []
+    for k in range(3):
+        acc = F(m[k] * v[0])
+        acc = F(F(m[4 + k] * v[1]) + acc)
+        acc = F(F(m[8 + k] * v[2]) + acc)
+        acc = F(F(m[12 + k] * F(w)) + acc)
+        out.append(acc)
+    return out
+
+
+def _walk(entries, o, d, t_min, t_max, inverses=None):
+    """Pre-order walk with skip links, f32 arithmetic; mirrors the device loop.  Tag 3 entries are the
+    markers around a transformed mesh: word 0 = 1 takes the ray to the mesh's space with the inverse
+    transform word 1 names, word 0 = 2 restores it."""
     ent_u = entries.view(np.uint32)
     n = len(entries)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        wo, wd = [F(x) for x in o], [F(x) for x in d]
+        o, d = wo, wd
         inv = [F(1.0) / d[k] for k in range(3)]
         best_t, best = F(t_max), 0xFFFFFFFF
         i = 0
@@ -264,6 +285,15 @@ def _walk(entries, o, d, t_min, t_max):
             tag = w >> 30
             if tag == 0:
                 i = (w & 0x3FFFFFFF) if _box_miss(e, o, inv, t_min, best_t) else i + 1
+            elif tag == 3:
+                if int(ent_u[i, 0]) == 1:
+                    m = inverses[int(ent_u[i, 1])]
+                    o, d = _mat_vec(m, wo, 1.0), _mat_vec(m, wd, 0.0)
+                else:
+                    assert int(ent_u[i, 0]) == 2
+                    o, d = wo, wd
+                inv = [F(1.0) / d[k] for k in range(3)]
+                i += 1
             else:
                 best_t, best = _prim_test(e, tag, int(ent_u[i, 7]), o, d, t_min, best_t, best)
                 i += 1
@@ -325,6 +355,92 @@ def test_flattened_entries_encode_reference_traversal(rt, ob, root):
         if prim != 0xFFFFFFFF:
             assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
     assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+
+
+def _nested_description(ob, seed, with_xforms):
+    """Containers inside containers (a Bvh of [spheres, a HittableList of [mesh, Bvh(axis 2) of spheres],
+    mesh]) and, optionally, transformed meshes."""
+    from helpers import random_mesh
+    rng = np.random.default_rng(seed)
+    mats, _, _ = random_scene(ob, seed)
+
+    def spheres(n):
+        sp = np.zeros(n, dtype=ob.sphere_dt)
+        sp["c"] = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+        sp["r"] = rng.uniform(0.2, 0.9, n).astype(np.float32)
+        sp["mat"] = rng.integers(0, 6, n)
+        return sp
+
+    def xf(kind):
+        if not with_xforms:
+            return None
+        m = np.eye(4, dtype=np.float32)
+        if kind == 0:
+            m[:3, 3] = [1.5, -0.75, 0.25]                              # Mat4::from_translation
+        elif kind == 1:
+            m[0, 0], m[1, 1], m[2, 2] = 1.5, 0.5, 2.0                  # a scale
+            m[:3, 3] = [-1.0, 0.5, 0.0]
+        else:
+            a = np.float32(0.7)                                        # rotation about z, shear and translation
+            m[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+            m[0, 2] = 0.3
+            m[:3, 3] = [0.2, 0.1, -0.6]
+        return m.T.reshape(16).copy()                                  # column-major
+
+    inner = ("bvh", [("spheres", spheres(5))], 2)
+    lst = ("list", [("mesh", random_mesh(ob, rng, 9, extent=3.0), xf(0)), inner, ("spheres", spheres(1))])
+    objects = [("spheres", spheres(4)), lst, ("mesh", random_mesh(ob, rng, 14, extent=3.0), xf(1)),
+               ("bvh", [("mesh", random_mesh(ob, rng, 1, extent=2.0), xf(2)), ("bvh", [], 1)]),
+               ("mesh", random_mesh(ob, rng, 6, extent=3.0))]
+    return mats, objects
+
+
+@pytest.mark.parametrize("root", [0, 2])
+@pytest.mark.parametrize("with_xforms", [False, True])
+def test_nested_containers_and_transformed_meshes(rt, ob, root, with_xforms):
+    """Bvh / HittableList objects inside one another flatten into the same pre-order array (a nested
+    Bvh is a subtree built with its own starting axis, a nested list a run of siblings without a box),
+    and a transformed mesh is its tree between an ENTER and a LEAVE marker.  Walking the entries (and
+    the linked units) must give the oracle's hits, which builds the containers as the reference's
+    constructors nest (shape.rs:55-57, 87-138) and transforms rays as Mesh::hit does (shape.rs:454)."""
+    mats, objects = _nested_description(ob, 61 + root, with_xforms)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root)
+    assert sc.num_prims == osc.num_prims == 4 + 9 + 5 + 1 + 14 + 1 + 6
+    ent = sc.entries()
+    u = ent.view(np.uint32)
+    markers = u[(u[:, 3] >> 30) == 3]
+    assert len(markers) == (6 if with_xforms else 0)
+    inverses = None
+    if with_xforms:
+        assert markers[:, 0].tolist() == [1, 2, 1, 2, 1, 2] and sorted(set(markers[:, 1].tolist())) == [0, 1, 2]
+        flat = [it for it in _flatten(objects) if it[0] == "mesh" and len(it) > 2 and it[2] is not None]
+        inverses = [ob.mat4_inverse(it[2]) for it in flat]             # transforms are numbered in the order added
+    rays = random_rays(ob, 12, 400, -4.0, 4.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 40
+    assert len(set(want["prim_id"].tolist())) > 15                     # spheres and triangles of several objects
+    for k in range(len(rays)):
+        prim, t = _walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf), inverses)
+        assert prim == want["prim_id"][k]
+        if prim != 0xFFFFFFFF:
+            assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
+    if not with_xforms:
+        units = sc.walk_units()
+        for k in range(0, len(rays), 3):
+            prim, t, _ = _walk_linked(units, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))
+            assert prim == want["prim_id"][k]
+    with pytest.raises(rt.RtError, match="not closed"):
+        s2 = rt.Scene.__new__(rt.Scene)
+        rt.Scene.__init__(s2, None, mats, [("bvh", [])], 0, _leave_open=True)
+
+
+def _flatten(objects):
+    for it in objects:
+        if it[0] in ("bvh", "list"):
+            yield from _flatten(it[1])
+        else:
+            yield it
 
 
 def test_child_links_of_the_ordered_walk(rt, ob):
@@ -556,6 +672,66 @@ def test_linked_units_keep_the_reference_order(rt, ob, root, top, monkeypatch):
         order = [unit_to_entry[v] for v in visited]
         assert order == sorted(order)                  # pre-order = the reference's visiting order
     assert (want["prim_id"] != 0xFFFFFFFF).sum() > 30
+
+
+def test_scene_cache_round_trip(rt, ob, tmp_path, monkeypatch):
+    """The binary scene cache: a 500 k-triangle soup committed with a cache directory writes
+    <key>.rtscene; committing the same description again loads it (no build) and gives identical
+    flattened arrays; another build mode or layout parameter is another key; a damaged file is
+    ignored and rebuilt."""
+    import time
+    rt.set_default_cache_dir(tmp_path)
+    try:
+        t0 = time.time()
+        a = rt.World.soup(None, 500_000, grid=16, seed=77)
+        t_build = time.time() - t0
+        assert a.scene.cache_state == rt.CACHE_STORED
+        files = sorted(tmp_path.glob("*.rtscene"))
+        assert len(files) == 1 and files[0].stat().st_size > 500_000 * 2 * 64
+        t0 = time.time()
+        b = rt.World.soup(None, 500_000, grid=16, seed=77)
+        t_load = time.time() - t0
+        assert b.scene.cache_state == rt.CACHE_LOADED
+        print(f"500 k triangles: generate + build + store {t_build:.2f} s, generate + load {t_load:.2f} s")
+        for get in (lambda s: s.entries(), lambda s: s.units(), lambda s: s.walk_units()):
+            x, y = get(a.scene), get(b.scene)
+            assert x.shape == y.shape and np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        assert a.scene.num_prims == b.scene.num_prims == 500_000 + 16 * 16 + 1
+        # another key: other triangles, another build mode, another layout
+        c = rt.World.soup(None, 500_000, grid=16, seed=78)
+        assert c.scene.cache_state == rt.CACHE_STORED and len(list(tmp_path.glob("*.rtscene"))) == 2
+        rt.set_default_build(rt.BUILD_SAH)
+        d = rt.World.soup(None, 500_000, grid=16, seed=77)
+        rt.set_default_build(rt.BUILD_REFERENCE)
+        assert d.scene.cache_state == rt.CACHE_STORED
+        monkeypatch.setenv("RT_LAYOUT_TOP", "0")
+        e = rt.World.soup(None, 500_000, grid=16, seed=77)
+        monkeypatch.delenv("RT_LAYOUT_TOP")
+        assert e.scene.cache_state == rt.CACHE_STORED and len(list(tmp_path.glob("*.rtscene"))) == 4
+        # a truncated file is not trusted
+        data = files[0].read_bytes()
+        files[0].write_bytes(data[:len(data) // 2])
+        f = rt.World.soup(None, 500_000, grid=16, seed=77)
+        assert f.scene.cache_state == rt.CACHE_STORED
+        assert np.array_equal(f.scene.walk_units().view(np.uint32), a.scene.walk_units().view(np.uint32))
+        assert files[0].stat().st_size == len(data)
+        # the hits of a cached scene are the oracle's (small scene through the core ABI)
+        mats, objects, _ = random_scene(ob, 5, n_spheres=12, n_meshes=2, tris_per_mesh=40, extent=4.0)
+        s1 = rt.Scene(None, mats, objects, 0, cache_dir=tmp_path)
+        s2 = rt.Scene(None, mats, objects, 0, cache_dir=tmp_path)
+        assert (s1.cache_state, s2.cache_state) == (rt.CACHE_STORED, rt.CACHE_LOADED)
+        osc = ob.Scene.from_description(mats, objects, 0)
+        rays = random_rays(ob, 3, 100, -5.0, 5.0)
+        want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+        ent = s2.entries()
+        for k in range(len(rays)):
+            assert _walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))[0] == want["prim_id"][k]
+        # a directory that does not exist: the scene is built, the store fails, nothing else does
+        s3 = rt.Scene(None, mats, objects, 0, cache_dir=tmp_path / "missing")
+        assert s3.cache_state == rt.CACHE_STORE_FAILED and s3.num_prims == s1.num_prims
+    finally:
+        rt.set_default_cache_dir(None)
+        rt.set_default_build(rt.BUILD_REFERENCE)
 
 
 def test_progressive_schedule_and_ppm(rt, tmp_path):
