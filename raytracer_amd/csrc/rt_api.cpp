@@ -138,6 +138,7 @@ struct rt_scene {
     int build_mode = RT_BUILD_REFERENCE;
     int traversal = RT_TRAVERSAL_AUTO;
     bool ordered_ok = false;
+    bool multi_child = false;           // a box with more than two children: no ordered walk (the octant walk is fine)
     bool auto_tuned = false;            // the first render has timed the forms of the closest-hit loop that apply
     uint32_t env_prim_wait = 0;         // RT_PRIM_WAIT, 0 when unset
     uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
@@ -428,6 +429,9 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
 static int apply_traversal(rt_scene* s, int mode) {
     if (s->dev.n_xforms != 0 && mode != RT_TRAVERSAL_AUTO && mode != RT_TRAVERSAL_PER_LANE)
         return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
+    if (mode == RT_TRAVERSAL_ORDERED && s->multi_child)
+        return fail(RT_ERR_UNSUPPORTED, "ordered traversal takes boxes of at most two children (no leaves of several triangles, "
+                                        "no list inside a Bvh); the octant traversal visits the same entries without that limit");
     if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
     if (mode == RT_TRAVERSAL_OCTANT) {
@@ -528,6 +532,7 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     s->dev.n_entries = (uint32_t)f.n_entries();
     s->dev.n_prims = (uint32_t)f.n_prims();
     s->ordered_ok = f.ordered_ok;
+    s->multi_child = f.multi_child;
     s->dev.n_units = (uint32_t)f.n_units();
     s->dev.n_walk = (uint32_t)f.n_walk();
     s->dev.walk_top_units = f.walk_top_units;
@@ -601,6 +606,7 @@ int rt_scene_commit(rt_scene* s) {
     s->dev.n_entries = (uint32_t)s->flat.n_entries();
     s->dev.n_prims = (uint32_t)s->flat.n_prims();
     s->ordered_ok = s->flat.ordered_ok;
+    s->multi_child = s->flat.multi_child;
     s->dev.n_units = (uint32_t)s->flat.n_units();
     s->dev.n_walk = (uint32_t)s->flat.n_walk();
     s->dev.walk_top_units = s->flat.walk_top_units;

@@ -211,10 +211,24 @@ struct Builder {
     // Binned SAH can peel one triangle off per level on a skewed mesh; below SAH_MAX_DEPTH levels the
     // nodes are halved instead, so the recursion (and every later walk over the tree) stays shallow.
     static constexpr int SAH_MAX_DEPTH = 40;
+    // Leaves of several triangles (sah_leaf > 1): a node of at most sah_leaf triangles is not split
+    // further; its box is followed by the triangles themselves, in file order, as siblings (the
+    // walks take a run of siblings one after the other, narrowing t_max as they go, exactly as they
+    // take a pair).  The subtree then needs fewer entries than the 2n - 1 reserved for it: the
+    // slots left over are marked in slot_unused and squeezed out once the mesh is complete.
+    uint32_t sah_leaf = 1;
+    std::vector<uint8_t> slot_unused;          // per entry slot of the mesh being built (offset slot_base)
+    size_t slot_base = 0;
     void fill_mesh_range_sah(uint32_t* idx, size_t n, size_t at, int fork_levels, int depth = 0) {
         if (n == 0) return;
         if (n == 1) { write_triangle(at, idx[0]); return; }
         write_box(at, padded_box(idx, n), at + mesh_entries(n));
+        if (n > 2 && n <= sah_leaf) {
+            std::sort(idx, idx + n);
+            for (size_t i = 0; i < n; i++) write_triangle(at + 1 + i, idx[i]);
+            for (size_t sl = at + 1 + n; sl < at + mesh_entries(n); sl++) slot_unused[sl - slot_base] = 1;
+            return;
+        }
         size_t half = n / 2;
         if (n > 2 && depth < SAH_MAX_DEPTH) {
             constexpr int BINS = 16;
@@ -283,6 +297,26 @@ struct Builder {
         }
     }
 
+    // drops the unused slots of the mesh at entries [at, at + count) and maps the skip links
+    void squeeze_mesh_slots(size_t at, size_t count) {
+        std::vector<uint32_t> new_of(count + 1);
+        uint32_t used = 0;
+        for (size_t k = 0; k < count; k++) { new_of[k] = (uint32_t)at + used; used += slot_unused[k] ? 0u : 1u; }
+        new_of[count] = (uint32_t)at + used;
+        for (size_t k = 0; k < count; k++) {
+            if (slot_unused[k]) continue;
+            float* e = entry(at + k);
+            uint32_t w;
+            std::memcpy(&w, &e[3], 4);
+            if ((w >> TAG_SHIFT) == TAG_BOX) {
+                w = (TAG_BOX << TAG_SHIFT) | new_of[(w & SKIP_MASK) - at];
+                std::memcpy(&e[3], &w, 4);
+            }
+            if (new_of[k] != at + k) std::memmove(entry(new_of[k]), e, ENTRY_FLOATS * sizeof(float));
+        }
+        out.entries.resize((size_t)new_of[count] * ENTRY_FLOATS);
+    }
+
     // the markers around the tree of a transformed mesh (rt_internal.hpp: END_CODE_*)
     void push_marker(uint32_t code, uint32_t xform_index) {
         float* e = entry(push_entry());
@@ -321,7 +355,10 @@ struct Builder {
                 const Box tb = tight_box(&idx[i], 1);
                 for (int k = 0; k < 3; k++) tri_cen[i * 3 + k] = tb.lo[k] + tb.hi[k];
             }
+            slot_base = at;
+            slot_unused.assign(sah_leaf > 2 ? mesh_entries(n) : 0, 0);
             fill_mesh_range_sah(idx.data(), n, at, 5);
+            if (sah_leaf > 2) squeeze_mesh_slots(at, mesh_entries(n));
         } else {
             fill_mesh_range(idx.data(), n, 0, at, 5);
         }
@@ -432,7 +469,11 @@ void annotate_children(FlatScene& out) {
         uint32_t link = 0;
         if (i + 1 < end) {
             const size_t second = end_of(i + 1);
-            if (second < end && out.ordered_ok) {
+            // (a box over a run of more than two siblings -- a leaf of several triangles, a
+            // HittableList inside a Bvh -- keeps link 0: its children are taken in array order, which
+            // the octant copies do and the stack of the ordered walk cannot)
+            if (second < end && end_of(second) != end) out.multi_child = true;
+            if (second < end && end_of(second) == end && out.ordered_ok) {
                 float c1[3], c2[3];
                 centre2(i + 1, c1);
                 centre2(second, c2);
@@ -668,12 +709,12 @@ uint64_t hash_bytes(uint64_t h, const void* data, size_t n) {
     std::memcpy(&tail, p + i, n - i);
     return mix(h ^ tail ^ ((uint64_t)n << 56));
 }
-constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '2'};
+constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '3'};
 struct CacheHeader {
     char magic[8];
     uint64_t key;
     uint64_t n_entries_f, n_units_f, n_walk_f, n_geo_f, n_meta, n_mat_f, n_xform_f;   // element counts of the arrays
-    uint32_t kinds_present, has_spheres, depth, ordered_ok, walk_top_units, reserved;
+    uint32_t kinds_present, has_spheres, depth, ordered_ok, walk_top_units, multi_child;
 };
 }  // namespace
 
@@ -681,8 +722,9 @@ uint64_t scene_cache_key(const std::vector<rt_material>& mats, const std::vector
                          const std::vector<SceneGroup>& groups, int root_kind, int build_mode) {
     uint64_t h = 0x5254414D44ull;
     const LayoutParams lp = layout_params();
-    const uint32_t head[8] = {(uint32_t)root_kind, (uint32_t)build_mode, lp.top_budget, lp.pair_align, lp.preorder,
-                              ENTRY_FLOATS, UNITS_END, (uint32_t)mats.size()};
+    const uint32_t leaf = (uint32_t)(std::getenv("RT_SAH_LEAF") ? std::atol(std::getenv("RT_SAH_LEAF")) : 1l);
+    const uint32_t head[9] = {(uint32_t)root_kind, (uint32_t)build_mode, lp.top_budget, lp.pair_align, lp.preorder,
+                              ENTRY_FLOATS, UNITS_END, (uint32_t)mats.size(), build_mode == RT_BUILD_SAH ? leaf : 0u};
     h = hash_bytes(h, head, sizeof(head));
     if (!mats.empty()) h = hash_bytes(h, mats.data(), mats.size() * sizeof(rt_material));
     for (const SceneObject& o : objects) {
@@ -721,7 +763,7 @@ bool scene_cache_load(const std::string& path, uint64_t key, FlatScene& out) {
     std::fclose(f);
     if (!ok || fs.units.size() < UNITS_END * 4 || fs.walk.size() < UNITS_END * 4) return false;
     fs.kinds_present = hd.kinds_present; fs.has_spheres = hd.has_spheres != 0; fs.depth = hd.depth;
-    fs.ordered_ok = hd.ordered_ok != 0; fs.walk_top_units = hd.walk_top_units;
+    fs.ordered_ok = hd.ordered_ok != 0; fs.walk_top_units = hd.walk_top_units; fs.multi_child = hd.multi_child != 0;
     out = std::move(fs);
     return true;
 }
@@ -737,7 +779,7 @@ bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& f
     hd.n_geo_f = fl.prim_geo.size(); hd.n_meta = fl.prim_meta.size(); hd.n_mat_f = fl.materials.size();
     hd.n_xform_f = fl.xforms.size();
     hd.kinds_present = fl.kinds_present; hd.has_spheres = fl.has_spheres ? 1u : 0u; hd.depth = fl.depth;
-    hd.ordered_ok = fl.ordered_ok ? 1u : 0u; hd.walk_top_units = fl.walk_top_units;
+    hd.ordered_ok = fl.ordered_ok ? 1u : 0u; hd.walk_top_units = fl.walk_top_units; hd.multi_child = fl.multi_child ? 1u : 0u;
     bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
     auto wr = [&](const auto& vec) {
         if (ok && !vec.empty()) ok = std::fwrite(vec.data(), sizeof(vec[0]), vec.size(), f) == vec.size();
@@ -761,6 +803,13 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     // primitive ids, per-primitive shading data, per-object boxes
     Builder b(mats, objects, out);
     b.sah = build_mode == RT_BUILD_SAH;
+    // Triangles per leaf of the opt-in trees: RT_SAH_LEAF, default 1.  Measured on one MI355X, leaves of
+    // 1 / 2 / 4 / 8: the 10 M-triangle soup 311 / 311 / 277 / 230 Mrays/s (octant walk 317 / 317 / 297 / 263:
+    // 342 -> 324 -> 287 box tests per ray, but 22 -> 47 -> 121 triangle tests, each three units against
+    // a box's two), cornell_box.obj 6.5 -> 5.5 Grays/s at 4, thing.obj 14.2 -> 12.5: where triangles are
+    // small against their spacing a box test is the cheaper way to cull them one by one.
+    if (b.sah)
+        b.sah_leaf = (uint32_t)std::min(16l, std::max(1l, std::getenv("RT_SAH_LEAF") ? std::atol(std::getenv("RT_SAH_LEAF")) : 1l));
     uint64_t prim = 0;
     for (SceneObject& o : objects) {
         o.prim_base = (uint32_t)prim;

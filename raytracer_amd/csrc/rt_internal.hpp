@@ -87,6 +87,7 @@ struct FlatScene {
     uint32_t walk_top_units = 0;       // units at the front of `walk` laid out breadth first
     uint32_t depth = 0;                // nesting depth of the boxes (slots the ordered walk's stack needs)
     bool ordered_ok = false;           // box entries carry the child links of the ordered walk
+    bool multi_child = false;          // some box has more than two children (the ordered walk's stack cannot take it)
     size_t n_entries() const { return entries.size() / ENTRY_FLOATS; }
     size_t n_prims() const { return prim_meta.size(); }
 };

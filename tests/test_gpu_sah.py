@@ -17,9 +17,11 @@ def _sah(rt, ctx, osc):
     return rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=rt.BUILD_SAH)
 
 
-def _check(rt, sc, rays, want, label):
+def _check(rt, sc, rays, want, label, ordered=False):
+    """(leaves of several triangles rule out the ordered walk's stack; the octant walk visits the same
+    entries in the same order without one)"""
     for mode in (rt.TRAVERSAL_PER_LANE, rt.TRAVERSAL_SWEEP if sc.num_entries <= 4096 else rt.TRAVERSAL_PER_LANE,
-                 rt.TRAVERSAL_ORDERED):
+                 rt.TRAVERSAL_ORDERED if ordered else rt.TRAVERSAL_OCTANT):
         sc.set_traversal(mode)
         got = sc.trace(rays)
         nan = np.isnan(want["t"])
@@ -49,11 +51,19 @@ def test_cornell(rt, ob, ctx, name):
     _check(rt, sc, rays, want, name)
 
 
-def test_world2_and_random_scenes(rt, ob, ctx):
+def test_world2_and_random_scenes(rt, ob, ctx, monkeypatch):
     osc = ob.Scene.world2(asset("thing.obj"), 1)
     rays = osc.record_rays(128, 96, 4, 6, cap=200000)
     want, _ = osc.trace(rays)
-    _check(rt, _sah(rt, ctx, osc), rays, want, "thing.obj")
+    _check(rt, _sah(rt, ctx, osc), rays, want, "thing.obj", ordered=True)
+    for leaf in ("2", "4", "8"):               # leaves of several triangles (opt-in: RT_SAH_LEAF)
+        monkeypatch.setenv("RT_SAH_LEAF", leaf)
+        sc = _sah(rt, ctx, osc)
+        _check(rt, sc, rays, want, f"thing.obj, leaves of {leaf}", ordered=leaf == "2")
+        if leaf != "2":
+            with pytest.raises(rt.RtError, match="at most two children"):
+                sc.set_traversal(rt.TRAVERSAL_ORDERED)
+    monkeypatch.delenv("RT_SAH_LEAF")
     for root in (0, 2):
         mats, objects, _ = random_scene(ob, 17 + root, n_spheres=40, n_meshes=3, tris_per_mesh=300)
         osc = ob.Scene.from_description(mats, objects, root)

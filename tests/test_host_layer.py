@@ -477,25 +477,38 @@ def test_child_links_of_the_ordered_walk(rt, ob):
     assert visits < st["box_tests"] + st["tri_tests"] + st["sph_tests"]
 
 
-def test_sah_build_keeps_format_and_hits(rt, ob):
-    """RT_BUILD_SAH moves only the split positions of mesh trees: every triangle is still one leaf,
-    every box still has exactly two children and the padded union of what is below it, the entry
-    count is unchanged, and both walks over the entries find the oracle's closest hits."""
+@pytest.mark.parametrize("leaf", [1, 4])
+def test_sah_build_keeps_format_and_hits(rt, ob, leaf, monkeypatch):
+    """RT_BUILD_SAH moves only the split positions of mesh trees.  With one triangle per leaf
+    (the default) every box still has exactly two children and the entry count is unchanged; with
+    RT_SAH_LEAF=4 a node of at most four triangles is a leaf: its box is followed by the triangles in
+    file order.  Either way every box is the padded union of what is below it, every primitive appears
+    once, and the walks over the entries find the oracle's closest hits."""
+    monkeypatch.setenv("RT_SAH_LEAF", str(leaf))
     mats, objects, _ = random_scene(ob, 41, n_spheres=12, n_meshes=2, tris_per_mesh=57, extent=5.0)
     osc = ob.Scene.from_description(mats, objects, 0)
     ref = rt.Scene(None, mats, objects, 0)
     sah = rt.Scene(None, mats, objects, 0, build=rt.BUILD_SAH)
     ent, u = sah.entries(), sah.entries().view(np.uint32)
-    assert len(ent) == ref.num_entries and sah.num_prims == ref.num_prims
-    assert not np.array_equal(ent, ref.entries())
+    assert sah.num_prims == ref.num_prims
+    assert (len(ent) == ref.num_entries) if leaf == 1 else (len(ent) < ref.num_entries - 20)
     tags = u[:, 3] >> 30
     assert sorted(u[tags != 0, 7].tolist()) == list(range(sah.num_prims))       # each primitive once
     end_of = lambda i: int(u[i, 3] & 0x3FFFFFFF) if tags[i] == 0 else i + 1
     pad = np.float32(0.0001)
+    big_leaves = 0
     for i in np.nonzero(tags == 0)[0]:
         end = end_of(i)
-        first = end_of(i + 1)                              # one child (an object-level leaf) or two
-        assert first == end or end_of(first) == end
+        first = end_of(i + 1)                              # one child (an object-level leaf), two, or a leaf's run
+        n_kids, c = 0, i + 1
+        while c < end:
+            n_kids, c = n_kids + 1, end_of(c)
+        if n_kids > 2:
+            assert leaf > 1 and n_kids <= leaf and all(tags[i + 1:end] == 1)
+            assert u[i + 1:end, 7].tolist() == sorted(u[i + 1:end, 7].tolist())     # file order
+            big_leaves += 1
+        else:
+            assert first == end or end_of(first) == end
         kids = np.arange(i + 1, end)
         tri = kids[tags[kids] == 1]
         if len(kids) + 1 == 2 * len(tri) - 1:              # a node of a mesh tree: n leaves, n - 1 boxes
@@ -504,10 +517,11 @@ def test_sah_build_keeps_format_and_hits(rt, ob):
             # vertices are stored as p0 and two edges; the sums round, so compare loosely
             np.testing.assert_allclose(ent[i, 0:3], pts.min(axis=0) - pad, atol=1e-5)
             np.testing.assert_allclose(ent[i, 4:7], pts.max(axis=0) + pad, atol=1e-5)
+    assert (big_leaves > 5) == (leaf > 1)
     rays = random_rays(ob, 9, 300, -6.0, 6.0)
     want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
     for k in range(len(rays)):
-        for walk in (_walk, _walk_ordered):
+        for walk in ((_walk, _walk_ordered) if leaf == 1 else (_walk,)):
             prim, t = walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf))[:2]
             assert prim == want["prim_id"][k]
             if prim != 0xFFFFFFFF:
