@@ -266,7 +266,21 @@ def main():
     ctx = rt.Context(local) if per_process else rt.Context(devices=devices)
     rt.set_default_build(rt.BUILD_SAH if args.build == "sah" else rt.BUILD_REFERENCE)
     t0 = time.time()
-    wld = make_world(ctx, kind)
+    if grouped and world > 1 and kind == "soup":
+        # one process per GPU: rank 0 flattens the scene and leaves it in the binary scene cache, the
+        # other ranks load it instead of building the same trees again on the same host cores
+        import tempfile
+        cache = os.environ.get("RT_SCENE_CACHE") or os.path.join(tempfile.gettempdir(), "rt_scene_cache")
+        os.makedirs(cache, exist_ok=True)
+        rt.set_default_cache_dir(cache)
+        if rank != 0:
+            dist.barrier()
+        wld = make_world(ctx, kind)
+        if rank == 0:
+            dist.barrier()
+        rt.set_default_cache_dir(None)
+    else:
+        wld = make_world(ctx, kind)
     build_s = time.time() - t0
     wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
                              "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,

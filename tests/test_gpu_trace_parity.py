@@ -171,8 +171,18 @@ def test_adversarial_rays(rt, ob, ctx, root):
     sc = mirror(rt, ctx, osc)
     rays = adversarial_rays(rt, 9, 120000, 560.0)
     rays["o"] = np.abs(rays["o"]) * np.float32([-1.0, -1.0, 1.0])          # inside the room
-    want, _ = osc.trace(rays)
-    _check_all_modes(rt, sc, rays, want)
+    # A mesh hands its rays through ray.transform(&inverse_transform) first (shape.rs:454), and the
+    # identity Mat4 may turn a -0.0 direction component into +0.0, flipping the sign of inv_d
+    # (math.rs:152-156).  Neither the oracle nor the kernels restate that for the identity, so for
+    # rays with a negative-zero direction component the agreement below is GPU <-> oracle only; the
+    # hit-parity claim against the reference covers the others.
+    neg0 = (np.signbit(rays["d"]) & (rays["d"] == 0.0)).any(axis=1)
+    assert 5000 < neg0.sum() < len(rays) // 2
+    claimed, unclaimed = rays[~neg0], rays[neg0]
+    want, _ = osc.trace(claimed)
+    _check_all_modes(rt, sc, claimed, want)
+    want, _ = osc.trace(unclaimed)                                          # GPU <-> oracle only
+    _check_all_modes(rt, sc, unclaimed, want)
 
 
 def test_nan_hit_leaves_every_later_box_open(rt, ob, ctx):

@@ -1,35 +1,50 @@
 #!/bin/bash
 # PMC passes of the per-batch kernel for every benchmark workload (run on the GPU box from the
-# repository root): three rocprofv3 --pmc runs per workload (SQ counters; FETCH_SIZE; WRITE_SIZE --
-# separate runs, the counter blocks do not all fit one), then tools/workload_table.py.
-#   bash tools/profile_workloads.sh <out dir> [build]      # build: reference (default) | sah
+# repository root):
+#   bash tools/profile_workloads.sh <out dir> [build] [workload ...]      # build: reference (default) | sah
+# Per workload: one unprofiled run to learn which form of the closest-hit loop the first render's
+# timing takes (the profiler serialises kernels, which would tip that timing), then three
+# rocprofv3 --pmc runs with that form pinned (SQ counters; FETCH_SIZE; WRITE_SIZE -- separate runs,
+# the counter blocks do not all fit one), then tools/workload_table.py, which prints the table and
+# writes <out dir>/pmc_workloads.json: the per-ray records bench.py turns into roofline fractions.
 set -e
 out=${1:-gpurun_out/workloads}
 build=${2:-reference}
+shift 2 || true
+wls=${@:-"cornell_plane_1024_1k world1_1080p_256 thing_glass_2048_512 cornell_full_512_64 soup_10m_4k_256"}
 root=$PWD
 cd /tmp && export TMPDIR=/tmp && cd $root
 mkdir -p $out
 names=""
-run() {   # name workload spp [extra bench.py arguments]
-    local name=$1 wl=$2 spp=$3 more=$4
+for wl in $wls; do
+    case $wl in
+        cornell_plane_1024_1k) spp=256;; world1_1080p_256) spp=64;; thing_glass_2048_512) spp=32;;
+        cornell_full_512_64) spp=256;; soup_10m_4k_256) spp=8;; *) spp=16;;
+    esac
+    name=${wl}_$build
+    timeout -k 10 600 python3 -u bench.py --no-cpu --steps 1 --warmup 1 --workload $wl --spp $spp --build $build > $out/${name}_plain.json 2> $out/${name}_plain.err \
+        || { tail -5 $out/${name}_plain.err; exit 1; }
+    form=$(python3 -c "import json,sys; print(json.loads(open('$out/${name}_plain.json').read().strip().splitlines()[-1])['config']['kernel_form'])")
+    case $form in
+        sweep) pin="--traversal sweep"; envs="RT_NO_AUTOTUNE=1";;
+        walk_lds) pin="--traversal per_lane"; envs="RT_NO_AUTOTUNE=1";;
+        walk_lds_refill) pin="--traversal per_lane"; envs="RT_REFILL=16";;
+        walk) pin="--traversal per_lane"; envs="RT_REFILL=0";;
+        walk_refill) pin="--traversal per_lane"; envs="RT_REFILL=16 RT_PRIM_WAIT=16";;
+        *) echo "unexpected form $form"; exit 1;;
+    esac
     for pass in sq f w; do
         case $pass in
             sq) ctr="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_SALU";;
             f) ctr="FETCH_SIZE";;
             w) ctr="WRITE_SIZE";;
         esac
-        timeout -s KILL 300 rocprofv3 --pmc $ctr -d $out/${name}_$pass -o $pass -- python3 bench.py --no-cpu --steps 1 --warmup 0 \
-            --workload $wl --spp $spp --build $build $more > $out/${name}_$pass.json 2> $out/${name}_$pass.err || { tail -5 $out/${name}_$pass.err; exit 1; }
+        # (the variables go through export: nothing may sit between rocprofv3's -- and the program)
+        ( export $envs; timeout -s KILL 400 rocprofv3 --pmc $ctr -d $out/${name}_$pass -o $pass -- python3 bench.py --no-cpu --steps 1 --warmup 0 \
+            --workload $wl --spp $spp --build $build $pin > $out/${name}_$pass.json 2> $out/${name}_$pass.err ) || { tail -5 $out/${name}_$pass.err; exit 1; }
     done
     names="$names $name"
-    echo "$name done"
-}
-# (the profiler serialises kernels, and a scene's first render times its candidate forms with two
-# kernels in flight: pin the form the unprofiled run takes)
-if [ "$build" = reference ]; then run c3_cornell_plane cornell_plane_1024_1k 256 "--traversal sweep"; else run c3_cornell_plane cornell_plane_1024_1k 256; fi
-run c2_world1 world1_1080p_256 64
-run c4_thing_glass thing_glass_2048_512 32
-run c1_cornell_full cornell_full_512_64 256
-RT_SOUP_TRIS=${RT_SOUP_TRIS:-10000000} run c5_soup soup_10m_4k_256 4
+    echo "$name done: form $form"
+done
 python3 tools/workload_table.py $out $names | tee $out/table.md
-rm -rf $out/*_sq $out/*_f $out/*_w          # the databases are large; the table and the bench lines stay
+rm -rf $out/*_sq $out/*_f $out/*_w          # the databases are large; the table, the records and the bench lines stay

@@ -1,34 +1,86 @@
 """Per-workload hardware table from PMC passes of k_path (rocpd databases written by rocprofv3):
-    python tools/workload_table.py <dir> name ...      # expects <dir>/<name>_{sq,f,w}/*_results.db and <name>_sq.json
-Columns: rays/s under the profiler, HBM GB/s (2*FETCH_SIZE + WRITE_SIZE), vector instructions per
-SIMD cycle (the part sustains one per 2.1-3.1 cycles), active lanes per vector instruction,
-resident waves per SIMD, share of wave time in s_waitcnt."""
+    python tools/workload_table.py <dir> name ...
+expects <dir>/<name>_{sq,f,w}/*_results.db and the bench lines <name>_{plain,sq}.json, prints the
+table and writes <dir>/pmc_workloads.json.
+
+Columns: rays/s under the profiler, HBM GB/s (2*FETCH_SIZE + WRITE_SIZE: FETCH_SIZE reads half of a
+16-byte-per-lane stream on gfx950), vector instructions per SIMD cycle (the part sustains one per
+2.1 cycles, 3.07 for packed f32), active lanes per vector instruction, resident waves per SIMD,
+share of wave time in s_waitcnt.
+
+The JSON holds, per "<workload>/<build>", what does not depend on how fast the run was: HBM bytes
+and vector instructions per ray, with the clock the chip held and the kernel form; bench.py
+multiplies them by the rate it measures itself."""
 import glob
 import json
+import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-def sums(path):
+
+def sums(path, pattern):
     db = sqlite3.connect(glob.glob(path + "/*_results.db")[0])
-    out, dur = {}, 0
-    for name, val in db.execute("select counter_name, sum(counter_value) from pmc_events where name like '%k_path%' group by counter_name"):
+    out = {}
+    for name, val in db.execute("select counter_name, sum(counter_value) from pmc_events where name like ? group by counter_name", (pattern,)):
         out[name] = val
-    dur = db.execute("select sum(duration) from (select distinct dispatch_id, duration from pmc_events where name like '%k_path%')").fetchone()[0]
-    return out, dur * 1e-9
+    dur = db.execute("select sum(duration) from (select distinct dispatch_id, duration from pmc_events where name like ?)", (pattern,)).fetchone()[0]
+    return out, (dur or 0) * 1e-9
 
 
-d = sys.argv[1]
-print("| workload | Mrays/s (profiled) | HBM GB/s | of 8 TB/s | VALU instr / SIMD cycle | active lanes / 64 | waves / SIMD | wait share |")
-print("|---|---|---|---|---|---|---|---|")
-for name in sys.argv[2:]:
-    sq, t = sums(f"{d}/{name}_sq")
-    f, tf = sums(f"{d}/{name}_f")
-    w, tw = sums(f"{d}/{name}_w")
-    j = json.loads(open(f"{d}/{name}_sq.json").read().strip().splitlines()[-1])
-    rays = j["config"]["rays_per_step"]
-    simd_cycles = sq["GRBM_GUI_ACTIVE"] / 8 * 1024
-    hbm = (2 * f["FETCH_SIZE"] / tf + w["WRITE_SIZE"] / tw) * 1024 / 1e9
-    print(f"| {j['config']['workload'].split(':')[0]} | {rays / t / 1e6:.0f} | {hbm:.0f} | {hbm / 8000:.2f} | "
-          f"{sq['SQ_INSTS_VALU'] / simd_cycles:.3f} | {sq['SQ_THREAD_CYCLES_VALU'] / sq['SQ_ACTIVE_INST_VALU']:.1f} | "
-          f"{sq['SQ_WAVE_CYCLES'] * 4 / simd_cycles:.1f} | {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.2f} |")
+def main():
+    d = sys.argv[1]
+    try:
+        from bench import kernel_source_hash
+        src_hash = kernel_source_hash()
+    except Exception:
+        src_hash = None
+    records = {}
+    print("| workload | form | Mrays/s (unprofiled) | Mrays/s (profiled) | HBM bytes / ray | HBM GB/s | of 8 TB/s | VALU instr / ray | "
+          "VALU instr / SIMD cycle | active lanes / 64 | waves / SIMD | wait share | clock GHz |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for name in sys.argv[2:]:
+        j = json.loads(open(f"{d}/{name}_sq.json").read().strip().splitlines()[-1])
+        plain = json.loads(open(f"{d}/{name}_plain.json").read().strip().splitlines()[-1])
+        form = j["config"]["kernel_form"]
+        assert form == plain["config"]["kernel_form"], (name, form, plain["config"]["kernel_form"])
+        sq, t = sums(f"{d}/{name}_sq", "%k_path%")
+        f, tf = sums(f"{d}/{name}_f", "%k_path%")
+        w, tw = sums(f"{d}/{name}_w", "%k_path%")
+        rays = j["config"]["rays_per_step"]
+        cycles_xcd = sq["GRBM_GUI_ACTIVE"] / 8                     # summed over the 8 XCDs
+        simd_cycles = cycles_xcd * 1024
+        clock = cycles_xcd / t / 1e9
+        hbm_per_ray = (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024 / rays
+        hbm = (2 * f["FETCH_SIZE"] / tf + w["WRITE_SIZE"] / tw) * 1024 / 1e9
+        valu_per_ray = sq["SQ_INSTS_VALU"] / rays
+        lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+        wl, build = j["config"]["workload"].split(":")[0], j["config"]["build"]
+        print(f"| {wl} ({build}) | {form} | {plain['value']:.0f} | {rays / t / 1e6:.0f} | {hbm_per_ray:.0f} | {hbm:.0f} | {hbm / 8000:.2f} | "
+              f"{valu_per_ray:.0f} | {sq['SQ_INSTS_VALU'] / simd_cycles:.3f} | {lanes:.1f} | "
+              f"{sq['SQ_WAVE_CYCLES'] * 4 / simd_cycles:.1f} | {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.2f} | {clock:.2f} |")
+        records[f"{wl}/{build}"] = {
+            "form": form, "rays_profiled": rays, "spp_profiled": j["config"]["workload"].split(", ")[1],
+            "hbm_bytes_per_ray": round(hbm_per_ray, 2),
+            "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
+            "valu_insts_per_ray": round(valu_per_ray, 2), "salu_insts_per_ray": round(sq["SQ_INSTS_SALU"] / rays, 2),
+            "active_lanes": round(lanes, 1), "waves_per_simd": round(sq["SQ_WAVE_CYCLES"] * 4 / simd_cycles, 2),
+            "wait_share": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3), "clock_ghz": round(clock, 3),
+            # SIMD cycles one vector instruction occupies with 8 waves per SIMD (tools/valu_rate.hip): 2.1 for
+            # plain f32 / select / compare, 3.07 for packed f32, of which the sweep's stream holds 45 %
+            "simd_cycles_per_valu_inst": 2.54 if form == "sweep" else 2.1,
+            "mrays_unprofiled": plain["value"], "mrays_profiled": round(rays / t / 1e6, 1),
+            "git_sha": os.environ.get("RT_GIT_SHA"), "source_hash": src_hash,
+            "command": f"tools/profile_workloads.sh (bench.py --no-cpu --steps 1 --warmup 0 --workload {wl} --build {build}, form pinned)",
+        }
+    with open(f"{d}/pmc_workloads.json", "w") as out:
+        json.dump({"note": "per-ray PMC records of the per-batch kernel k_path, written by tools/workload_table.py; "
+                           "hbm_bytes_per_ray = (2*FETCH_SIZE + WRITE_SIZE) KiB / rays of the profiled step "
+                           "(the launches of that step only: the form is pinned, so the first render probes nothing)",
+                   "records": records}, out, indent=1)
+        out.write("\n")
+
+
+if __name__ == "__main__":
+    main()
