@@ -467,6 +467,19 @@ static int apply_traversal(rt_scene* s, int mode) {
     s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
     s->dev.sweep = mode == RT_TRAVERSAL_SWEEP ||
                    (mode == RT_TRAVERSAL_AUTO && s->dev.n_entries <= SWEEP_MAX_ENTRIES) ? 1u : 0u;
+    s->dev.split_top = 0;
+    s->dev.deep_wait = 0;
+    if (const char* e = std::getenv("RT_SPLIT")) {     // experiment: the split walk, RT_SPLIT = lanes a fetch from memory waits for
+        const uint32_t wait = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
+        const uint64_t top_bytes = (uint64_t)s->dev.walk_top_units * 16u;
+        if (wait > 0 && mode != RT_TRAVERSAL_ORDERED && mode != RT_TRAVERSAL_OCTANT && !s->dev.sweep && s->dev.n_xforms == 0 &&
+            top_bytes > 0 && top_bytes <= SPLIT_TOP_MAX_BYTES && s->dev.walk_top_units < s->dev.n_walk && !s->dev.lds_walk) {
+            s->dev.split_top = s->dev.walk_top_units;      // (whole sibling groups: no entry straddles the boundary)
+            s->dev.deep_wait = wait;
+            if (s->dev.refill == 0) s->dev.refill = 16;
+            s->auto_tuned = true;
+        }
+    }
     if (s->dev.n_xforms != 0) {                // one form follows the transform markers: the plain walk from memory
         s->dev.sweep = 0;
         s->dev.refill = 0;

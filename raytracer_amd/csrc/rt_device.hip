@@ -255,6 +255,63 @@ __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32
     return true;
 }
 
+// The split walk: the first `top` units of the array (the top levels of the trees, which every ray
+// visits) are read from a copy in LDS, the rest from memory -- and the fetches from memory are
+// batched.  A wave-wide load occupies the CU's address unit for at least ten cycles however few
+// lanes take part, and that unit is what the walks from memory wait for; LDS has a path of its own.
+// A lane whose cursor leaves the top therefore does not fetch at once: it holds PEND_WORD in the tag
+// word of e.a and waits until `deep_wait` lanes do (or no lane has an entry in hand), and one pair
+// of loads then serves them all, while the lanes in the top go on out of LDS.  Every ray still
+// visits its entries in the reference's order; only when a lane gets its next entry changes.
+constexpr uint32_t PEND_WORD = 0xFFFFFFFFu;            // tag bits = TAG_END, but not the end units' word
+constexpr uint32_t ENDED_WORD = TAG_END << TAG_SHIFT;
+typedef const float4 __attribute__((address_space(3)))* lds_units_ptr;   // (typed as LDS: its reads can never become flat loads)
+struct SplitCfg { lds_units_ptr lds; uint32_t top, deep_wait; };
+template <bool COUNT>
+__device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, const SplitCfg& sp, uint32_t prim_wait,
+                                                LaneRay& r, LaneEntry& e, float t_min, Counts& cnt) {
+    const uint32_t w = f2u(e.a.w);
+    const uint32_t tag = w >> TAG_SHIFT;
+    const bool at_box = tag == TAG_BOX;
+    const bool at_prim = tag - TAG_TRI < 2u;
+    const bool pending = w == PEND_WORD;
+    const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim), mq = __ballot(pending);
+    if ((mb | mp | mq) == 0ull) return false;
+    RT_UTIL_TRIP(cnt);
+    bool moved = false;
+    if (at_box) {
+        if (COUNT) cnt.box++;
+        r.i = box_step(e.a, e.b, r, t_min);
+        moved = true;
+    }
+    const bool run_prims = mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait;      // wave-uniform
+    if (run_prims && at_prim) {
+        if (tag == TAG_TRI) {
+            if (COUNT) cnt.tri++;
+            float4 c;
+            if (r.i < sp.top) c = sp.lds[r.i + 2]; else c = ent[r.i + 2];
+            tri_step(e.a, e.b, c, r, t_min);
+            r.i = f2u(c.w);
+        } else {
+            if (COUNT) cnt.sph++;
+            sphere_step(e.a, e.b, r, t_min);
+            r.i = f2u(e.b.y);
+        }
+        moved = true;
+    }
+    const bool in_top = r.i < sp.top;
+    if (moved && in_top) { e.a = sp.lds[r.i]; e.b = sp.lds[r.i + 1]; }
+    const bool want = pending || (moved && !in_top);
+    if (moved && !in_top) e.a.w = u2f(PEND_WORD);
+    // lanes that hold an entry after this trip: those that just read one from LDS and those that wait at a primitive
+    const unsigned long long m_has = __ballot((moved && in_top) || (at_prim && !run_prims));
+    const unsigned long long m_want = __ballot(want);
+    if (m_want != 0ull && ((uint32_t)__popcll(m_want) >= sp.deep_wait || m_has == 0ull)) {
+        if (want) { e.a = ent[r.i]; e.b = ent[r.i + 1]; }
+    }
+    return true;
+}
+
 template <bool COUNT, bool OCT = false>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                             bool valid, float ox,
@@ -948,9 +1005,9 @@ __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 // (finish_ray + queueing) and take the next rays of the segment.  Every ray is still walked by one
 // lane in the reference's order; only which lane and when changes, and nothing downstream depends
 // on that (queues are compacted per kind, radiance is stored per path slot).
-template <bool COUNT, bool OCT = false>
+template <bool COUNT, bool OCT = false, bool SPLIT = false>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
-                                             uint32_t refill_min, const float4* __restrict__ mats,
+                                             uint32_t refill_min, const SplitCfg& sp, const float4* __restrict__ mats,
                                              const uint32_t* __restrict__ prim_meta, const float4* __restrict__ A,
                                              const float4* __restrict__ B, const float4* __restrict__ C,
                                              uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -968,7 +1025,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, end_word);
     LaneEntry e{ended, ended, ended, ended};
     for (;;) {
-        const bool live = (f2u(e.a.w) >> TAG_SHIFT) != TAG_END;
+        // (in the split walk a lane that waits for a unit from memory holds PEND_WORD there: it is live)
+        const bool live = SPLIT ? f2u(e.a.w) != ENDED_WORD : (f2u(e.a.w) >> TAG_SHIFT) != TAG_END;
         const unsigned long long m_live = __ballot(live);
         const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
@@ -996,13 +1054,15 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
-                    fetch_entry(ent, r.i, e);
+                    if (SPLIT) { e.a = sp.lds[r.i]; e.b = sp.lds[r.i + 1]; }    // (the split walk's top holds unit 0)
+                    else fetch_entry(ent, r.i, e);
                 }
                 next = min(n, next + n_idle);
                 continue;
             }
         }
-        walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt);
+        if (SPLIT) walk_trip_split<COUNT>(ent, sp, prim_wait, r, e, t_min, cnt);
+        else walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt);
     }
 }
 
@@ -1053,12 +1113,17 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
         }
     } else if (SWEEP == 5 || SWEEP == 6) {
         walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
-                            sc.refill, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
-                            sky_intensity, n0, n1, n2, cnt);
+                            sc.refill, SplitCfg{nullptr, 0u, 0u}, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base,
+                            n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
+    } else if (SWEEP == 10) {
+        walk_segment<COUNT, false, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, sc.refill,
+                                         SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, mats, sc.prim_meta,
+                                         A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
+                                         n1, n2, cnt);
     } else if (SWEEP == 8) {
-        walk_segment<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, mats, sc.prim_meta,
-                                  A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1,
-                                  n2, cnt);
+        walk_segment<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
+                                  mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
+                                  sky_intensity, n0, n1, n2, cnt);
     } else {
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
@@ -1305,16 +1370,17 @@ __device__ __forceinline__ void stage_fence() {
 #define RT_LDS_BLOCK 512
 #endif
 template <int SWEEP>
-__global__ void __launch_bounds__(SWEEP == 4 || SWEEP == 6 ? RT_LDS_BLOCK : RT_WAVE)
+__global__ void __launch_bounds__(SWEEP == 4 || SWEEP == 6 || SWEEP == 10 ? RT_LDS_BLOCK : RT_WAVE)
     __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
        uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
-    const uint32_t wpb = SWEEP == 4 || SWEEP == 6 ? RT_LDS_BLOCK / 64 : RT_WPB;
+    const uint32_t wpb = SWEEP == 4 || SWEEP == 6 || SWEEP == 10 ? RT_LDS_BLOCK / 64 : RT_WPB;
     const uint32_t seg = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (SWEEP == 4 || SWEEP == 6) {
+    if (SWEEP == 4 || SWEEP == 6 || SWEEP == 10) {
         const float4* src = (const float4*)sc.walk;
         float4* dst = (float4*)lds_stack;
-        for (uint32_t i = threadIdx.x; i < sc.n_walk + UNITS_END; i += RT_LDS_BLOCK) dst[i] = src[i];
+        const uint32_t n_copy = SWEEP == 10 ? sc.split_top : sc.n_walk + UNITS_END;   // (split walk: the top only)
+        for (uint32_t i = threadIdx.x; i < n_copy; i += RT_LDS_BLOCK) dst[i] = src[i];
         __syncthreads();                       // before any wave of the workgroup may leave
     }
     if (seg >= g.n_seg) return;
@@ -1494,6 +1560,11 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
         if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
+        return check_launch();
+    }
+    if (sc.split_top && sc.refill && !sc.ordered && !sc.octant) {
+        const size_t bytes = (size_t)sc.split_top * 16u;
+        RT_PATH_LDS(10);
         return check_launch();
     }
     if (sc.octant) { if (sc.refill) RT_PATH(8); else RT_PATH(7); }

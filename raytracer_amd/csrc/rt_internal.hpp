@@ -163,6 +163,8 @@ struct DevScene {
     uint32_t n_xforms;        // > 0: the scene is walked by the form that follows ENTER / LEAVE markers
     const void* units_oct;    // float4[8 * (n_units + UNITS_END)]: the unit array once per direction octant (octant walk)
     uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
+    uint32_t split_top;       // > 0: the fused kernel keeps the first split_top units of `walk` in LDS (split walk)
+    uint32_t deep_wait;       // split walk: lanes that must wait for a unit from memory before the wave fetches for them
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default
@@ -170,6 +172,8 @@ constexpr uint32_t SWEEP_MAX_ENTRIES = 192;
 // unit arrays up to this size are copied to LDS by every 8-wave workgroup of the per-lane walk
 // (three such workgroups fit the 160 KB of a CU: 6 waves per SIMD)
 constexpr uint32_t LDS_WALK_MAX_BYTES = 52u * 1024u;
+// the split walk keeps at most this much of the top of the trees in LDS (four 8-wave workgroups per CU)
+constexpr uint32_t SPLIT_TOP_MAX_BYTES = 36u * 1024u;
 
 constexpr uint32_t MAX_DEPTH = 64;
 

@@ -1,5 +1,8 @@
 """Ad-hoc parity campaign: random scenes x random and adversarial rays, every traversal form against
-the oracle (primitive id exact, t bit-exact; the opt-in near-first walks: t and hit / miss).  Run on a GPU box: python tests/fuzz_parity.py [seeds]  (not collected by pytest: a long-running campaign)"""
+the oracle (primitive id exact, t bit-exact; the opt-in near-first walks and the SAH trees: t and
+hit / miss).  Every third seed nests containers at random and gives half of its meshes a random
+invertible transform.  Run on a GPU box: python tests/fuzz_parity.py [seeds]  (not collected by
+pytest: a long-running campaign)"""
 import os
 import sys
 
@@ -10,7 +13,40 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import raytracer_amd as rt                      # noqa: E402
 from oracle import binding as ob                # noqa: E402
-from helpers import adversarial_rays, random_rays, random_scene   # noqa: E402
+from helpers import adversarial_rays, random_mesh, random_rays, random_scene   # noqa: E402
+
+
+def random_xform(rng):
+    """A random invertible affine map, column major: rotation x scale x shear, then a translation."""
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    m = np.eye(4)
+    shear = np.eye(3)
+    shear[0, 1], shear[1, 2] = rng.uniform(-0.5, 0.5, 2)
+    m[:3, :3] = q @ np.diag(rng.uniform(0.3, 2.5, 3) * rng.choice([-1.0, 1.0], 3)) @ shear
+    m[:3, 3] = rng.uniform(-3.0, 3.0, 3)
+    return m.astype(np.float32).T.reshape(16).copy()
+
+
+def nested_objects(rng, depth=0):
+    """Spheres, meshes (half of them transformed) and containers inside containers, at random."""
+    out = []
+    for _ in range(int(rng.integers(1, 5))):
+        kind = int(rng.integers(0, 4 if depth < 3 else 2))
+        if kind == 0:
+            n = int(rng.integers(1, 12))
+            sp = np.zeros(n, dtype=ob.sphere_dt)
+            sp["c"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+            sp["r"] = rng.uniform(0.1, 1.2, n).astype(np.float32)
+            sp["mat"] = rng.integers(0, 6, n)
+            out.append(("spheres", sp))
+        elif kind == 1:
+            tris = random_mesh(ob, rng, int(rng.integers(1, 200)), extent=4.0)
+            out.append(("mesh", tris, random_xform(rng)) if rng.random() < 0.5 else ("mesh", tris))
+        elif kind == 2:
+            out.append(("bvh", nested_objects(rng, depth + 1), int(rng.integers(0, 3))))
+        else:
+            out.append(("list", nested_objects(rng, depth + 1)))
+    return out
 
 
 def main():
@@ -23,24 +59,28 @@ def main():
         root = [0, 2][seed % 2]
         mats, objects, _ = random_scene(ob, seed, n_spheres=int(rng.integers(0, 80)), n_meshes=int(rng.integers(0, 4)),
                                         tris_per_mesh=int(rng.integers(1, 400)))
+        if seed % 3 == 0:
+            objects = nested_objects(rng)
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
+        sah = rt.Scene(ctx, mats, objects, root, build=rt.BUILD_SAH)
         batches = [("random", random_rays(ob, seed + 100, 200000, -12.0, 12.0)), ("adversarial", adversarial_rays(rt, seed, 100000, 12.0))]
         for name, rays in batches:
             want, _ = osc.trace(rays)
-            for mode, label in ((rt.TRAVERSAL_PER_LANE, "per-lane"), (rt.TRAVERSAL_SWEEP, "sweep"),
-                                (rt.TRAVERSAL_ORDERED, "ordered"), (rt.TRAVERSAL_OCTANT, "octant")):
+            for scene, mode, label in ((sc, rt.TRAVERSAL_PER_LANE, "per-lane"), (sc, rt.TRAVERSAL_SWEEP, "sweep"),
+                                       (sc, rt.TRAVERSAL_ORDERED, "ordered"), (sc, rt.TRAVERSAL_OCTANT, "octant"),
+                                       (sah, rt.TRAVERSAL_PER_LANE, "SAH per-lane"), (sah, rt.TRAVERSAL_OCTANT, "SAH octant")):
                 try:
-                    sc.set_traversal(mode)
-                except rt.RtError:                  # trees nested too deep for the near-first walks
-                    continue
-                n = len(rays) if sc.num_entries <= 600 or mode != rt.TRAVERSAL_SWEEP else 30000
-                got = sc.trace(rays[:n])
+                    scene.set_traversal(mode)
+                except rt.RtError:                  # trees nested too deep for the near-first walks; the forms
+                    continue                        # that refuse transformed meshes or boxes of several children
+                n = len(rays) if scene.num_entries <= 600 or mode != rt.TRAVERSAL_SWEEP else 30000
+                got = scene.trace(rays[:n])
                 w = want[:n]
                 hit = (w["prim_id"] != rt.MISS) & ~(np.isnan(w["t"]) & np.isnan(got["t"]))   # NaN payloads differ by hardware
                 m_prim = int((got["prim_id"] != w["prim_id"]).sum())
                 m_t = int((got["t"][hit].view(np.uint32) != w["t"][hit].view(np.uint32)).sum())
-                if mode in (rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT):
+                if mode in (rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT) or scene is sah:
                     # not the reference's visiting order: t and hit / miss must agree, the primitive may
                     # differ where two primitives tie in t (counted)
                     ties += m_prim
@@ -49,7 +89,8 @@ def main():
                     bad += 1
                     k = np.nonzero(got["prim_id"] != w["prim_id"])[0][:3]
                     print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {rays[k]}")
-        print(f"seed {seed}: {sc.num_entries} entries, root {root}, hits {(want['prim_id'] != rt.MISS).mean():.2f} ok", flush=True)
+        print(f"seed {seed}: {sc.num_entries} entries{' (nested)' if seed % 3 == 0 else ''}, root {root}, "
+              f"hits {(want['prim_id'] != rt.MISS).mean():.2f} ok", flush=True)
     print("mismatching batches:", bad, " primitives that differ under the near-first walks (ties in t):", ties)
     return 1 if bad else 0
 

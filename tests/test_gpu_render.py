@@ -239,6 +239,38 @@ def test_refilled_walk_renders_the_same_frame(rt, ob, ctx, monkeypatch):
     monkeypatch.delenv("RT_REFILL", raising=False)
 
 
+@pytest.mark.parametrize("top", ["2048", "200"])
+def test_split_walk_renders_the_same_frame(rt, ob, ctx, monkeypatch, top):
+    """The split walk (an experiment, RT_SPLIT = lanes a fetch from memory waits for): the top of the
+    trees is read from a copy in LDS and the fetches from memory are batched.  Which lane gets its next
+    entry when changes, nothing else: the frame equals the staged frame bit for bit, with a large and
+    a small top, on the reference and the SAH tree."""
+    monkeypatch.setenv("RT_LAYOUT_TOP", top)
+    osc = ob.Scene.cornell_box(asset("cornell_box.obj"))
+    w, h, spp = 96, 80, 48
+    cam = product_camera(rt, osc, w, h)
+    for build in (rt.BUILD_REFERENCE, rt.BUILD_SAH):
+        monkeypatch.delenv("RT_REFILL", raising=False)
+        monkeypatch.delenv("RT_SPLIT", raising=False)
+        plain = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=build)
+        plain.set_traversal(rt.TRAVERSAL_PER_LANE)
+        scenes = []
+        for split, refill in (("1", "16"), ("8", "16"), ("24", "8"), ("64", "40")):
+            monkeypatch.setenv("RT_REFILL", refill)
+            monkeypatch.setenv("RT_SPLIT", split)
+            sc = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=build)
+            sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+            scenes.append(sc)
+        for max_paths in (0, w * h * 7):
+            staged, st0 = plain.render(cam, rt.Scene.params(w, h, spp, 8, osc.sky, max_paths=max_paths, flags=rt.RENDER_STAGED))
+            for sc in scenes:
+                img, st = sc.render(cam, rt.Scene.params(w, h, spp, 8, osc.sky, max_paths=max_paths))
+                assert st["rays_traced"] == st0["rays_traced"]
+                assert np.array_equal(img.view(np.uint32), staged.view(np.uint32))
+    monkeypatch.delenv("RT_REFILL", raising=False)
+    monkeypatch.delenv("RT_SPLIT", raising=False)
+
+
 def test_progressive_render_delivers_the_reference_block_events(rt, ob, ctx):
     """rt_world_render_progressive: steps 10, 20, 40, 50 of a 50-spp frame; after each, every 64x64
     block (edge blocks clipped) in j-then-i order, tonemapped with the samples so far, with red

@@ -35,7 +35,7 @@ for wl in $wls; do
     esac
     for pass in sq f w; do
         case $pass in
-            sq) ctr="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_SALU";;
+            sq) ctr="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR TA_TA_BUSY_sum";;
             f) ctr="FETCH_SIZE";;
             w) ctr="WRITE_SIZE";;
         esac

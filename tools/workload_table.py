@@ -6,7 +6,8 @@ table and writes <dir>/pmc_workloads.json.
 Columns: rays/s under the profiler, HBM GB/s (2*FETCH_SIZE + WRITE_SIZE: FETCH_SIZE reads half of a
 16-byte-per-lane stream on gfx950), vector instructions per SIMD cycle (the part sustains one per
 2.1 cycles, 3.07 for packed f32), active lanes per vector instruction, resident waves per SIMD,
-share of wave time in s_waitcnt.
+share of wave time in s_waitcnt, wave-wide vector memory instructions per ray and the share of
+time the CUs' address units (TA) were busy.
 
 The JSON holds, per "<workload>/<build>", what does not depend on how fast the run was: HBM bytes
 and vector instructions per ray, with the clock the chip held and the kernel form; bench.py
@@ -38,8 +39,8 @@ def main():
         src_hash = None
     records = {}
     print("| workload | form | Mrays/s (unprofiled) | Mrays/s (profiled) | HBM bytes / ray | HBM GB/s | of 8 TB/s | VALU instr / ray | "
-          "VALU instr / SIMD cycle | active lanes / 64 | waves / SIMD | wait share | clock GHz |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+          "VALU instr / SIMD cycle | active lanes / 64 | waves / SIMD | wait share | clock GHz | VMEM instr / ray | TA busy |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name in sys.argv[2:]:
         j = json.loads(open(f"{d}/{name}_sq.json").read().strip().splitlines()[-1])
         plain = json.loads(open(f"{d}/{name}_plain.json").read().strip().splitlines()[-1])
@@ -56,15 +57,20 @@ def main():
         hbm = (2 * f["FETCH_SIZE"] / tf + w["WRITE_SIZE"] / tw) * 1024 / 1e9
         valu_per_ray = sq["SQ_INSTS_VALU"] / rays
         lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+        vmem_per_ray = (sq.get("SQ_INSTS_VMEM_RD", 0) + sq.get("SQ_INSTS_VMEM_WR", 0)) / rays
+        # TA_TA_BUSY_sum adds up the 256 address units, GRBM_GUI_ACTIVE the 8 XCDs
+        ta_busy = sq.get("TA_TA_BUSY_sum", 0) / 256 / cycles_xcd
         wl, build = j["config"]["workload"].split(":")[0], j["config"]["build"]
         print(f"| {wl} ({build}) | {form} | {plain['value']:.0f} | {rays / t / 1e6:.0f} | {hbm_per_ray:.0f} | {hbm:.0f} | {hbm / 8000:.2f} | "
               f"{valu_per_ray:.0f} | {sq['SQ_INSTS_VALU'] / simd_cycles:.3f} | {lanes:.1f} | "
-              f"{sq['SQ_WAVE_CYCLES'] * 4 / simd_cycles:.1f} | {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.2f} | {clock:.2f} |")
+              f"{sq['SQ_WAVE_CYCLES'] * 4 / simd_cycles:.1f} | {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.2f} | {clock:.2f} | "
+              f"{vmem_per_ray:.2f} | {ta_busy:.2f} |")
         records[f"{wl}/{build}"] = {
             "form": form, "rays_profiled": rays, "spp_profiled": j["config"]["workload"].split(", ")[1],
             "hbm_bytes_per_ray": round(hbm_per_ray, 2),
             "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
             "valu_insts_per_ray": round(valu_per_ray, 2), "salu_insts_per_ray": round(sq["SQ_INSTS_SALU"] / rays, 2),
+            "vmem_insts_per_ray": round(vmem_per_ray, 3), "ta_busy": round(ta_busy, 3),
             "active_lanes": round(lanes, 1), "waves_per_simd": round(sq["SQ_WAVE_CYCLES"] * 4 / simd_cycles, 2),
             "wait_share": round(sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"], 3), "clock_ghz": round(clock, 3),
             # SIMD cycles one vector instruction occupies with 8 waves per SIMD (tools/valu_rate.hip): 2.1 for
