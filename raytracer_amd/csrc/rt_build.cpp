@@ -8,6 +8,7 @@
 // Built with -ffp-contract=off: box and edge values must be the plain IEEE f32 results.
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -160,36 +161,82 @@ struct Builder {
         return b;
     }
 
-    // Mesh::build_bvh (shape.rs:264-290) on idx[0..n), written in pre-order at entries
+    // Mesh::build_bvh (shape.rs:264-290) on the triangles r[0..n), written in pre-order at entries
     // [at, at + 2n - 1): a subtree of n >= 1 triangles always takes 2n - 1 entries, so every
     // node's place is known before its children are built and the two halves of a big node can
-    // be built by different threads (they sort disjoint index ranges and write disjoint entries).
+    // be built by different threads (they sort disjoint ranges and write disjoint entries).
+    // Every record carries its triangle's three sort keys, so a sort moves records and never looks
+    // a key up elsewhere; big ranges are sorted by a stable radix sort (sort_keys).  Returns the
+    // tight box of the range: a node's box is the union of its halves' (minima and maxima are exact,
+    // so the union equals compute_aabb's scan over all the vertices, shape.rs:218-233, except for the
+    // sign of a zero, which the padding removes: -0.0 - 0.0001 = +0.0 - 0.0001).
     static size_t mesh_entries(size_t n) { return n ? 2 * n - 1 : 0; }
-    void fill_mesh_range(uint32_t* idx, size_t n, int axis, size_t at, int fork_levels) {
-        if (n == 0) return;                    // MeshBvhNode::None never hits
-        if (n == 1) { write_triangle(at, idx[0]); return; }
-        if (n == 2) {
-            write_box(at, padded_box(idx, 2), at + 3);
-            write_triangle(at + 1, idx[1]);    // left = pop() = last
-            write_triangle(at + 2, idx[0]);    // right = pop() = first
+    struct TriKey { float k[3]; uint32_t i; };     // Triangle::get_aabb().min (shape.rs:195-199) and the triangle
+    // an unsigned whose order is the floats' order, -0.0 and +0.0 alike (they compare equal)
+    static uint32_t order_bits(float f) {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        if (u == 0x80000000u) u = 0u;
+        return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    // r[0..n) in ascending k[axis], equal keys in their old order: slice::sort_by with partial_cmp
+    // (shape.rs:268-272; a stable sort).  tmp: n records of scratch.
+    static void sort_keys(TriKey* r, TriKey* tmp, size_t n, int axis) {
+        if (n < 4096) {
+            std::stable_sort(r, r + n, [axis](const TriKey& a, const TriKey& b) { return a.k[axis] < b.k[axis]; });
             return;
         }
-        const float* key = tri_min.data();
-        std::stable_sort(idx, idx + n, [key, axis](uint32_t a, uint32_t b) {
-            return key[a * 3 + axis] < key[b * 3 + axis];
-        });
-        const size_t half = n / 2;             // split_off(len / 2)
+        TriKey *src = r, *dst = tmp;               // least significant digit first: 11 + 11 + 10 bits
+        std::vector<size_t> count(2048);
+        for (int pass = 0; pass < 3; pass++) {
+            const int shift = pass * 11;
+            const uint32_t mask = pass == 2 ? 0x3FFu : 0x7FFu;
+            std::fill(count.begin(), count.end(), 0);
+            for (size_t i = 0; i < n; i++) count[(order_bits(src[i].k[axis]) >> shift) & mask]++;
+            size_t sum = 0;
+            for (size_t& c : count) { const size_t here = c; c = sum; sum += here; }
+            for (size_t i = 0; i < n; i++) dst[count[(order_bits(src[i].k[axis]) >> shift) & mask]++] = src[i];
+            std::swap(src, dst);
+        }
+        std::memcpy(r, tmp, n * sizeof(TriKey));   // (three passes: the result stands in tmp)
+    }
+    Box triangle_box(uint32_t local) const {
+        const rt_triangle& t = mesh->tris[local];
+        Box b{{t.p[0][0], t.p[0][1], t.p[0][2]}, {t.p[0][0], t.p[0][1], t.p[0][2]}};
+        grow_point(b, t.p[1]); grow_point(b, t.p[2]);
+        return b;
+    }
+    static Box padded(Box b) {                     // compute_aabb's last step: +-0.0001 on every face
+        for (int k = 0; k < 3; k++) b.hi[k] += 0.0001f;
+        for (int k = 0; k < 3; k++) b.lo[k] -= 0.0001f;
+        return b;
+    }
+    Box fill_mesh_range(TriKey* r, TriKey* tmp, size_t n, int axis, size_t at, int fork_levels) {
+        if (n == 0) return box_infinity();         // MeshBvhNode::None never hits
+        if (n == 1) { write_triangle(at, r[0].i); return triangle_box(r[0].i); }
+        if (n == 2) {
+            const Box tight = surrounding(triangle_box(r[0].i), triangle_box(r[1].i));
+            write_box(at, padded(tight), at + 3);
+            write_triangle(at + 1, r[1].i);        // left = pop() = last
+            write_triangle(at + 2, r[0].i);        // right = pop() = first
+            return tight;
+        }
+        sort_keys(r, tmp, n, axis);
+        const size_t half = n / 2;                 // split_off(len / 2)
         const size_t left_at = at + 1, right_at = left_at + mesh_entries(half);
         const int next = (axis + 1) % 3;
-        write_box(at, padded_box(idx, n), at + mesh_entries(n));   // before the halves get re-sorted
+        Box left_box, right_box;
         if (fork_levels > 0 && n >= 65536) {
-            std::thread left([=]() { fill_mesh_range(idx, half, next, left_at, fork_levels - 1); });
-            fill_mesh_range(idx + half, n - half, next, right_at, fork_levels - 1);
+            std::thread left([&, this]() { left_box = fill_mesh_range(r, tmp, half, next, left_at, fork_levels - 1); });
+            right_box = fill_mesh_range(r + half, tmp + half, n - half, next, right_at, fork_levels - 1);
             left.join();
         } else {
-            fill_mesh_range(idx, half, next, left_at, 0);
-            fill_mesh_range(idx + half, n - half, next, right_at, 0);
+            left_box = fill_mesh_range(r, tmp, half, next, left_at, 0);
+            right_box = fill_mesh_range(r + half, tmp + half, n - half, next, right_at, 0);
         }
+        const Box tight = surrounding(left_box, right_box);
+        write_box(at, padded(tight), at + mesh_entries(n));
+        return tight;
     }
 
     // The opt-in tree: same entry format, boxes and leaves, but every node is split where a binned
@@ -344,12 +391,12 @@ struct Builder {
             grow_point(b, o.tris[i].p[1]); grow_point(b, o.tris[i].p[2]);
             tri_min[i * 3] = b.lo[0]; tri_min[i * 3 + 1] = b.lo[1]; tri_min[i * 3 + 2] = b.lo[2];
         }
-        std::vector<uint32_t> idx(n);
-        std::iota(idx.begin(), idx.end(), 0u);
         const size_t at = out.n_entries();
         out.entries.resize(out.entries.size() + mesh_entries(n) * ENTRY_FLOATS, 0.0f);
         // Mesh::hit enters at the root node (shape.rs:455); up to 2^5 threads on a big mesh
         if (sah) {
+            std::vector<uint32_t> idx(n);
+            std::iota(idx.begin(), idx.end(), 0u);
             tri_cen.resize(n * 3);
             for (size_t i = 0; i < n; i++) {
                 const Box tb = tight_box(&idx[i], 1);
@@ -360,7 +407,9 @@ struct Builder {
             fill_mesh_range_sah(idx.data(), n, at, 5);
             if (sah_leaf > 2) squeeze_mesh_slots(at, mesh_entries(n));
         } else {
-            fill_mesh_range(idx.data(), n, 0, at, 5);
+            std::vector<TriKey> recs(n), tmp(n);
+            for (size_t i = 0; i < n; i++) recs[i] = TriKey{{tri_min[i * 3], tri_min[i * 3 + 1], tri_min[i * 3 + 2]}, (uint32_t)i};
+            fill_mesh_range(recs.data(), tmp.data(), n, 0, at, 5);
         }
         mesh = nullptr;
     }
@@ -880,7 +929,17 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
         for (long it : g.items)
             if (it >= (long)objects.size() || -1 - it >= (long)groups.size()) return "internal error: bad container item";
     }
+    // RT_BUILD_TIMING=1: seconds per phase of the flattening on stderr
+    const bool timing = std::getenv("RT_BUILD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rt build] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     b.compute_group_boxes();
+    lap("geometry tables, boxes");
     std::vector<long> ids(groups[0].items);    // the children of World.hittable
     if (root_kind == RT_ROOT_SINGLE) {
         if (ids.size() != 1) return "RT_ROOT_SINGLE needs exactly one object";
@@ -893,11 +952,15 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     } else {
         return "unknown root kind";
     }
+    lap("trees");
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
     annotate_children(out);
+    lap("child links");
     if (!pack_units(out)) return "scene too large for 30-bit unit links";
+    lap("pre-order units");
     const LayoutParams lp = layout_params();
     if (!pack_walk_units(out, lp.top_budget, lp.pair_align)) return "scene too large for 30-bit unit links";
+    lap("linked units");
     if (!out.xforms.empty()) out.ordered_ok = false;       // the near-first walks do not follow the transform markers
     return std::string();
 }

@@ -265,7 +265,12 @@ __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32
 // visits its entries in the reference's order; only when a lane gets its next entry changes.
 constexpr uint32_t PEND_WORD = 0xFFFFFFFFu;            // tag bits = TAG_END, but not the end units' word
 constexpr uint32_t ENDED_WORD = TAG_END << TAG_SHIFT;
-typedef const float4 __attribute__((address_space(3)))* lds_units_ptr;   // (typed as LDS: its reads can never become flat loads)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 __attribute__((address_space(3)))* lds_units_ptr;   // (typed as LDS: its reads can never become flat loads)
+__device__ __forceinline__ float4 lds_unit(lds_units_ptr p, uint32_t i) {
+    const f32x4 v = p[i];
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 struct SplitCfg { lds_units_ptr lds; uint32_t top, deep_wait; };
 template <bool COUNT>
 __device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, const SplitCfg& sp, uint32_t prim_wait,
@@ -289,7 +294,7 @@ __device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, 
         if (tag == TAG_TRI) {
             if (COUNT) cnt.tri++;
             float4 c;
-            if (r.i < sp.top) c = sp.lds[r.i + 2]; else c = ent[r.i + 2];
+            if (r.i < sp.top) c = lds_unit(sp.lds, r.i + 2); else c = ent[r.i + 2];
             tri_step(e.a, e.b, c, r, t_min);
             r.i = f2u(c.w);
         } else {
@@ -300,7 +305,7 @@ __device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, 
         moved = true;
     }
     const bool in_top = r.i < sp.top;
-    if (moved && in_top) { e.a = sp.lds[r.i]; e.b = sp.lds[r.i + 1]; }
+    if (moved && in_top) { e.a = lds_unit(sp.lds, r.i); e.b = lds_unit(sp.lds, r.i + 1); }
     const bool want = pending || (moved && !in_top);
     if (moved && !in_top) e.a.w = u2f(PEND_WORD);
     // lanes that hold an entry after this trip: those that just read one from LDS and those that wait at a primitive
@@ -1054,7 +1059,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
-                    if (SPLIT) { e.a = sp.lds[r.i]; e.b = sp.lds[r.i + 1]; }    // (the split walk's top holds unit 0)
+                    if (SPLIT) { e.a = lds_unit(sp.lds, r.i); e.b = lds_unit(sp.lds, r.i + 1); }    // (the split walk's top holds unit 0)
                     else fetch_entry(ent, r.i, e);
                 }
                 next = min(n, next + n_idle);
