@@ -182,7 +182,8 @@ struct Builder {
     // r[0..n) in ascending k[axis], equal keys in their old order: slice::sort_by with partial_cmp
     // (shape.rs:268-272; a stable sort).  tmp: n records of scratch.
     static void sort_keys(TriKey* r, TriKey* tmp, size_t n, int axis) {
-        if (n < 4096) {
+        // (RT_BUILD_NO_RADIX=1: the comparison sort at every size, for tests of the radix sort against it)
+        if (n < 4096 || std::getenv("RT_BUILD_NO_RADIX")) {
             std::stable_sort(r, r + n, [axis](const TriKey& a, const TriKey& b) { return a.k[axis] < b.k[axis]; });
             return;
         }

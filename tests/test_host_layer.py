@@ -267,7 +267,7 @@ def _mat_vec(m, v, w):
     return out
 
 
-def _walk(entries, o, d, t_min, t_max, inverses=None):
+def _walk(entries, o, d, t_min, t_max, inverses=None, count=False):
     """Pre-order walk with skip links, f32 arithmetic; mirrors the device loop.  Tag 3 entries are the
     markers around a transformed mesh: word 0 = 1 takes the ray to the mesh's space with the inverse
     transform word 1 names, word 0 = 2 restores it."""
@@ -279,11 +279,13 @@ def _walk(entries, o, d, t_min, t_max, inverses=None):
         inv = [F(1.0) / d[k] for k in range(3)]
         best_t, best = F(t_max), 0xFFFFFFFF
         i = 0
+        n_box = n_prim = 0
         while i < n:
             e = entries[i]
             w = int(ent_u[i, 3])
             tag = w >> 30
             if tag == 0:
+                n_box += 1
                 i = (w & 0x3FFFFFFF) if _box_miss(e, o, inv, t_min, best_t) else i + 1
             elif tag == 3:
                 if int(ent_u[i, 0]) == 1:
@@ -295,9 +297,10 @@ def _walk(entries, o, d, t_min, t_max, inverses=None):
                 inv = [F(1.0) / d[k] for k in range(3)]
                 i += 1
             else:
+                n_prim += 1
                 best_t, best = _prim_test(e, tag, int(ent_u[i, 7]), o, d, t_min, best_t, best)
                 i += 1
-    return best, best_t
+    return (best, best_t, n_box, n_prim) if count else (best, best_t)
 
 
 def _walk_ordered(entries, o, d, t_min, t_max):
@@ -355,6 +358,45 @@ def test_flattened_entries_encode_reference_traversal(rt, ob, root):
         if prim != 0xFFFFFFFF:
             assert F(t).view(np.uint32) == want["t"][k].view(np.uint32)
     assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+
+
+def test_radix_sorted_mesh_tree_equals_the_comparison_sorted_one(rt, ob, monkeypatch):
+    """Mesh::build_bvh sorts by Triangle::get_aabb().min[axis] with a stable comparison sort
+    (shape.rs:268-272).  Ranges of 4096 triangles and more are sorted by a stable radix sort on the key
+    bits here: on a mesh whose keys are full of duplicates, zeros of both signs, denormals, negative
+    and huge values, the flattened tree must equal the comparison-sorted one bit for bit, and a walk
+    over it must give the oracle's hits and the oracle's visit counts (the oracle sorts by comparison)."""
+    rng = np.random.default_rng(77)
+    n = 9000
+    pool = np.array([0.0, -0.0, 1e-42, -1e-42, 1.0, -1.0, 1.0000001, 3e30, -3e30, 0.5, -0.5, 2.0 ** -126, 7.25],
+                    dtype=np.float32)
+    tr = np.zeros(n, dtype=ob.triangle_dt)
+    base = pool[rng.integers(0, len(pool), (n, 1, 3))]
+    fine = rng.uniform(-2.0, 2.0, (n, 1, 3)).astype(np.float32)
+    corner = np.where(rng.random((n, 1, 3)) < 0.6, base, fine)               # the minimum corner: the sort key
+    tr["p"] = corner + np.abs(rng.uniform(0.0, 0.7, (n, 3, 3))).astype(np.float32) * (rng.random((n, 3, 1)) < 0.7)
+    tr["p"][:, 0] = corner[:, 0]
+    tr["n0"] = [0.0, 0.0, 1.0]
+    tr["mat"] = 0
+    mats, _, _ = random_scene(ob, 3)
+    objects = [("mesh", tr)]
+    sc = rt.Scene(None, mats, objects, 1)
+    monkeypatch.setenv("RT_BUILD_NO_RADIX", "1")
+    plain = rt.Scene(None, mats, objects, 1)
+    monkeypatch.delenv("RT_BUILD_NO_RADIX")
+    ent = sc.entries()
+    assert np.array_equal(ent.view(np.uint32), plain.entries().view(np.uint32))
+    assert np.array_equal(sc.walk_units().view(np.uint32), plain.walk_units().view(np.uint32))
+    osc = ob.Scene.from_description(mats, objects, 1)
+    rays = random_rays(ob, 9, 60, -2.5, 2.5)
+    want, st = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    boxes = tris = 0
+    for k in range(len(rays)):
+        prim, t, nb, nt = _walk(ent, rays["o"][k], rays["d"][k], F(0.001), F(np.inf), count=True)
+        assert prim == want["prim_id"][k]
+        boxes += nb
+        tris += nt
+    assert (boxes, tris) == (st["box_tests"], st["tri_tests"])
 
 
 def _nested_description(ob, seed, with_xforms):
