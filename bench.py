@@ -105,9 +105,8 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
     counts: HBM (PMC bytes per ray x measured rays/s against the 8 TB/s peak), vector-instruction
     issue (PMC instructions per ray x measured rays/s, priced at the SIMD cycles per instruction this
     part sustains with 8 waves per SIMD, tools/valu_rate.hip: 2.1 plain, 3.07 packed f32) and the
-    vector memory path of a CU (PMC load/store instructions per ray x measured rays/s, priced at the
-    10 CU cycles a wave-wide access takes at best, tools/ta_rate.hip).  The bound is the largest
-    fraction.  The algorithmic rate of the scope table's per-ray formula is reported
+    CUs' address units (PMC busy cycles per ray x measured rays/s: the share of time they are busy).
+    The bound is the largest fraction.  The algorithmic rate of the scope table's per-ray formula is reported
     beside it: it exceeds the HBM peak when the flattened tree is served from the caches."""
     out = {"kernel": extra.pop("kernel"), "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "GB/s": round(algo_gbs, 1) if algo_gbs else None,
                                                          "of_hbm_peak": round(algo_gbs / (HBM_PEAK_GBS * n_gpus), 4) if algo_gbs else None,
@@ -130,16 +129,18 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
     out["valu_issue"] = {"achieved_inst_per_simd_cycle": round(issue_rate, 4), "peak_inst_per_simd_cycle": round(issue_peak, 4),
                          "frac": round(issue_frac, 4), "insts_per_ray": round(rec["valu_insts_per_ray"], 1),
                          "active_lanes_per_inst": rec.get("active_lanes"), "clock_ghz": rec["clock_ghz"]}
-    # third candidate: the CU's vector memory path, which takes at least VMEM_CYCLES cycles per wave-wide
-    # load or store however few lanes take part (tools/ta_rate.hip: 10 for up to 16 scattered lanes or
-    # a coalesced wave, 12.5 at 32 random lanes, 21.7 at 64)
+    # third candidate: the CUs' address units (TA), through which every vector memory instruction goes.
+    # TA_TA_BUSY over the profiled run gives busy cycles per ray; at this run's rate that is the share
+    # of time the units are busy.  (Priced instead at the 10 CU cycles a wave-wide access takes at
+    # best, tools/ta_rate.hip, the instruction count gives the lower figure reported beside it.)
     vmem_frac = None
-    if rec.get("vmem_insts_per_ray") is not None:
+    if rec.get("ta_busy") is not None and rec.get("mrays_profiled"):
+        vmem_frac = rec["ta_busy"] * per_gpu / (rec["mrays_profiled"] * 1e6)
         vmem_rate = rec["vmem_insts_per_ray"] * per_gpu / (N_CUS * rec["clock_ghz"] * 1e9)      # per CU cycle
-        vmem_frac = vmem_rate * VMEM_CYCLES
-        out["vmem_issue"] = {"achieved_inst_per_cu_cycle": round(vmem_rate, 4), "peak_inst_per_cu_cycle": round(1.0 / VMEM_CYCLES, 4),
-                             "frac": round(vmem_frac, 4), "insts_per_ray": round(rec["vmem_insts_per_ray"], 2),
-                             "address_unit_busy_profiled": rec.get("ta_busy")}
+        out["address_unit"] = {"busy_share": round(vmem_frac, 4), "busy_share_profiled": rec["ta_busy"],
+                               "vmem_insts_per_ray": round(rec["vmem_insts_per_ray"], 2),
+                               "vmem_insts_per_cu_cycle": round(vmem_rate, 4),
+                               "frac_at_10_cycles_per_inst": round(vmem_rate * VMEM_CYCLES, 4)}
     best = max(hbm_frac, issue_frac, vmem_frac or 0.0)
     if best == hbm_frac:
         out.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(hbm_frac, 1.0), 4)})
@@ -147,8 +148,8 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
         out.update({"bound": "valu_issue", "achieved": round(issue_rate, 4), "peak": round(issue_peak, 4),
                     "unit": "vector instructions per SIMD cycle", "frac": round(min(issue_frac, 1.0), 4)})
     else:
-        out.update({"bound": "vmem_issue", "achieved": round(vmem_rate, 4), "peak": round(1.0 / VMEM_CYCLES, 4),
-                    "unit": "vector memory instructions per CU cycle", "frac": round(min(vmem_frac, 1.0), 4)})
+        out.update({"bound": "address_unit", "achieved": round(vmem_frac, 4), "peak": 1.0,
+                    "unit": "share of time the CUs' address units are busy", "frac": round(min(vmem_frac, 1.0), 4)})
     out["traffic"] = int(rec["hbm_bytes_per_ray"] * extra.get("rays_per_launch", 0)) or None
     out["traffic_unit"] = "HBM bytes per launch of the dominant kernel: PMC bytes per ray x this run's rays per launch"
     out["pmc"] = {"file": "profiles/pmc_workloads.json", "profiled_form": rec.get("form"), "this_run_form": form,
