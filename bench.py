@@ -33,7 +33,7 @@ from raytracer_amd import distributed as D                     # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, GB/s
 N_SIMDS = 1024                 # 256 CUs x 4
 N_CUS = 256
-VMEM_CYCLES = 10.0             # CU cycles per wave-wide vector memory instruction, at best (tools/ta_rate.hip)
+VMEM_CYCLES = 16.0             # CU cycles per wave-wide 16-byte vector memory instruction, at best (tools/ta_rate.hip)
 WORKLOADS = {
     # name: (constructor, width, height, spp, max depth)
     "cornell_plane_1024_1k": ("cornell_plane", 1024, 1024, 1024, 6),
@@ -131,7 +131,7 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
                          "active_lanes_per_inst": rec.get("active_lanes"), "clock_ghz": rec["clock_ghz"]}
     # third candidate: the CUs' address units (TA), through which every vector memory instruction goes.
     # TA_TA_BUSY over the profiled run gives busy cycles per ray; at this run's rate that is the share
-    # of time the units are busy.  (Priced instead at the 10 CU cycles a wave-wide access takes at
+    # of time the units are busy.  (Priced instead at the 16 CU cycles a wave-wide access takes at
     # best, tools/ta_rate.hip, the instruction count gives the lower figure reported beside it.)
     vmem_frac = None
     if rec.get("ta_busy") is not None and rec.get("mrays_profiled"):
@@ -140,7 +140,7 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
         out["address_unit"] = {"busy_share": round(vmem_frac, 4), "busy_share_profiled": rec["ta_busy"],
                                "vmem_insts_per_ray": round(rec["vmem_insts_per_ray"], 2),
                                "vmem_insts_per_cu_cycle": round(vmem_rate, 4),
-                               "frac_at_10_cycles_per_inst": round(vmem_rate * VMEM_CYCLES, 4)}
+                               "frac_at_16_cycles_per_inst": round(vmem_rate * VMEM_CYCLES, 4)}
     best = max(hbm_frac, issue_frac, vmem_frac or 0.0)
     if best == hbm_frac:
         out.update({"bound": "hbm", "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(min(hbm_frac, 1.0), 4)})

@@ -257,7 +257,7 @@ __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32
 
 // The split walk: the first `top` units of the array (the top levels of the trees, which every ray
 // visits) are read from a copy in LDS, the rest from memory -- and the fetches from memory are
-// batched.  A wave-wide load occupies the CU's address unit for at least ten cycles however few
+// batched.  A wave-wide load occupies the CU's address unit for at least 16 cycles however few
 // lanes take part, and that unit is what the walks from memory wait for; LDS has a path of its own.
 // A lane whose cursor leaves the top therefore does not fetch at once: it holds PEND_WORD in the tag
 // word of e.a and waits until `deep_wait` lanes do (or no lane has an entry in hand), and one pair

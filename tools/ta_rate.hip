@@ -1,5 +1,5 @@
 // What a wave-wide global load costs the address unit of a CU on this GPU, by load width, by which
-// lanes take part and by how the addresses fall: cycles of one CU per load instruction with 8
+// lanes take part and by how the addresses fall: cycles of one CU per load instruction with up to 8
 // resident waves per SIMD, every wave keeping 8 independent loads in flight.  The table the lanes
 // read is 16 KB, so every access is an L1 hit and the figure is the address path's, not the
 // memory's.  Build: hipcc --offload-arch=gfx950 -O2 tools/ta_rate.hip -o tools/ta_rate
@@ -132,13 +132,11 @@ int main() {
                 // shader clock from the ratio of the two counters of workgroup 0 (s_memrealtime runs at 100 MHz)
                 const double ghz = (double)h[0] / ((double)h[1] * 10.0);
                 const double loads_per_cu = 32.0 * ITERS * 8;               // wave-wide load instructions
-                double mean_dt = 0;                                         // every workgroup is resident from start to end
-                for (int b = 0; b < blocks; b++) mean_dt += (double)h[(size_t)b * 2];
-                mean_dt /= blocks;
-                const double cyc = mean_dt / loads_per_cu;
+                // (by wall time: the workgroups of a launch are not all resident from its start to its end, so a
+                // workgroup's own cycle count undercounts; rocprofv3's TA_TA_BUSY per load agrees with this figure)
+                const double cyc = ms * 1e-3 * ghz * 1e9 / loads_per_cu;
                 const char* names[] = {"dword", "dwordx2", "dwordx4", "ds_b128"};
-                printf("%-10s %-28s %-26s %12.3f %14.2f   (%.2f GHz; by wall time %.2f)\n", names[kind], addr_names[am], mk.name, ms, cyc, ghz,
-                       ms * 1e-3 * ghz * 1e9 / loads_per_cu);
+                printf("%-10s %-28s %-26s %12.3f %14.2f   (%.2f GHz)\n", names[kind], addr_names[am], mk.name, ms, cyc, ghz);
                 CHECK(hipEventDestroy(e0)); CHECK(hipEventDestroy(e1));
             }
         }
