@@ -51,10 +51,11 @@ def nested_objects(rng, depth=0):
 
 def main():
     n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     ctx = rt.Context(0)
     bad = 0
     ties = 0
-    for seed in range(1, n_seeds + 1):
+    for seed in range(first, first + n_seeds):
         rng = np.random.default_rng(seed)
         root = [0, 2][seed % 2]
         mats, objects, _ = random_scene(ob, seed, n_spheres=int(rng.integers(0, 80)), n_meshes=int(rng.integers(0, 4)),
@@ -64,6 +65,7 @@ def main():
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
         sah = rt.Scene(ctx, mats, objects, root, build=rt.BUILD_SAH)
+        tie_log = []
         batches = [("random", random_rays(ob, seed + 100, 200000, -12.0, 12.0)), ("adversarial", adversarial_rays(rt, seed, 100000, 12.0))]
         for name, rays in batches:
             want, _ = osc.trace(rays)
@@ -81,16 +83,25 @@ def main():
                 m_prim = int((got["prim_id"] != w["prim_id"]).sum())
                 m_t = int((got["t"][hit].view(np.uint32) != w["t"][hit].view(np.uint32)).sum())
                 if mode in (rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT) or scene is sah:
+                    # a hit distance that overflowed (inf, or the NaN of an overflowed sphere discriminant, which
+                    # the reference accepts and hands on as t_max) ties with every other such hit: which one
+                    # a walk reports depends on its visiting order, like the primitive of any tie
+                    both_overflowed = ~np.isfinite(w["t"]) & ~np.isfinite(got["t"])
+                    m_t = int((got["t"][hit & ~both_overflowed].view(np.uint32) != w["t"][hit & ~both_overflowed].view(np.uint32)).sum())
                     # not the reference's visiting order: t and hit / miss must agree, the primitive may
                     # differ where two primitives tie in t (counted)
                     ties += m_prim
+                    if m_prim:
+                        tie_log.append(f"{label} {name}: {m_prim}")
                     m_prim = int(((got["prim_id"] == rt.MISS) != (w["prim_id"] == rt.MISS)).sum())
                 if m_prim or m_t:
                     bad += 1
-                    k = np.nonzero(got["prim_id"] != w["prim_id"])[0][:3]
-                    print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {rays[k]}")
+                    k = np.nonzero((got["prim_id"] != w["prim_id"]) if m_prim else
+                                   (hit & (got["t"].view(np.uint32) != w["t"].view(np.uint32))))[0][:3]
+                    print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {rays[k]}: "
+                          f"t {got['t'][k]} / {w['t'][k]}, primitive {got['prim_id'][k]} / {w['prim_id'][k]}")
         print(f"seed {seed}: {sc.num_entries} entries{' (nested)' if seed % 3 == 0 else ''}, root {root}, "
-              f"hits {(want['prim_id'] != rt.MISS).mean():.2f} ok", flush=True)
+              f"hits {(want['prim_id'] != rt.MISS).mean():.2f} ok" + (f"  ties: {'; '.join(tie_log)}" if tie_log else ""), flush=True)
     print("mismatching batches:", bad, " primitives that differ under the near-first walks (ties in t):", ties)
     return 1 if bad else 0
 
