@@ -15,7 +15,8 @@ timeout -k 10 900 python3 -u bench.py --no-cpu --workload soup_10m_4k_256 --buil
 python3 - $out <<'PY'
 import json, sys
 for l in open(sys.argv[1]):
-    d = json.loads(l); r = d["roofline"]
-    print(f'{d["config"]["workload"].split(":")[0]:24s} build {d["config"].get("build","?"):9s} {d["value"]:9.1f} Mrays/s  '
-          f'{d["ms_per_step"]:9.1f} ms/frame  tests/ray {r["tests_per_ray"]}  algorithmic {r["achieved"]} GB/s')
+    d = json.loads(l); r = d["roofline"]; t = r["algorithmic"]["tests_per_ray"]
+    print(f'{d["config"]["workload"].split(":")[0]:24s} build {d["config"].get("build","?"):9s} form {d["config"]["kernel_form"]:16s} '
+          f'{d["value"]:9.1f} Mrays/s {d["ms_per_step"]:9.1f} ms/frame  tests/ray box {t["box"]} tri {t["tri"]} sph {t["sph"]}  '
+          f'bound {r["bound"]} {r["frac"]}')
 PY
