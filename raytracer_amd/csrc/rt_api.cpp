@@ -640,7 +640,12 @@ int rt_scene_commit(rt_scene* s) {
         r->build_mode = s->build_mode;
         r->traversal = s->traversal;
         rc = upload_scene(r, s->flat);
-        if (rc) return rc;
+        if (rc) {                              // leave no half-made copies behind: a later commit starts afresh
+            const std::string why = g_last_error;
+            for (rt_scene* made : s->replicas) rt_scene_destroy(made);
+            s->replicas.clear();
+            return fail(rc, why);
+        }
         r->committed = true;
     }
     // the host copies of the geometry are no longer needed
