@@ -247,7 +247,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even for one rank")
     ap.add_argument("--max-paths", type=int, default=0)
-    ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered", "octant"], default="auto")
+    ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered", "octant", "wide"], default="auto")
     args = ap.parse_args()
 
     # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 on
@@ -303,7 +303,7 @@ def main():
     build_s = time.time() - t0
     wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
                              "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,
-                             "octant": rt.TRAVERSAL_OCTANT}[args.traversal])
+                             "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[args.traversal])
     cam = wld.camera(width, height)
     accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
 

@@ -110,7 +110,8 @@ typedef struct {
  * traversal is RT_TRAVERSAL_AUTO the first render times the forms that apply and keeps the faster,
  * so two runs may differ here (never in the frame) */
 enum { RT_FORM_SWEEP = 0, RT_FORM_WALK = 1, RT_FORM_WALK_LDS = 2, RT_FORM_WALK_REFILL = 3,
-       RT_FORM_WALK_LDS_REFILL = 4, RT_FORM_ORDERED = 5, RT_FORM_OCTANT = 6, RT_FORM_OCTANT_REFILL = 7 };
+       RT_FORM_WALK_LDS_REFILL = 4, RT_FORM_ORDERED = 5, RT_FORM_OCTANT = 6, RT_FORM_OCTANT_REFILL = 7,
+       RT_FORM_WIDE = 8 };
 
 typedef struct {
     uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */
@@ -216,9 +217,17 @@ int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CA
  * copy of its octant with the same skip links as PER_LANE.  Eight times the tree memory (the
  * 10 M-triangle scene: about 6.5 GB of the 288 GB) buys the ordered walk's culling at the plain walk's
  * cost per visit.  Same caveat on ties and same limits as ORDERED; needs a device context.
+ * WIDE is opt-in too and walks another tree: on its first use the scene's flattened trees (of either
+ * build mode) are collapsed into nodes of up to eight children whose boxes the node stores itself,
+ * quantised to 8 bits per plane on a grid of the node (80 bytes per node, always enclosing the true
+ * boxes), with every primitive a leaf of its own.  A lane fetches a node, tests its eight boxes at
+ * once, and visits the children that were hit nearest first, the rest waiting on a per-lane stack
+ * of one word per level.  The primitive tests are the reference's, so t is theirs; the caveat on
+ * ties and on box tests within rounding is that of ORDERED.  Fails with RT_ERR_UNSUPPORTED for
+ * scenes with transformed meshes, trees deeper than 60 wide levels or of 2^24 node slots and more.
  * May be called before or after rt_scene_commit(). */
 enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2, RT_TRAVERSAL_ORDERED = 3,
-       RT_TRAVERSAL_OCTANT = 4 };
+       RT_TRAVERSAL_OCTANT = 4, RT_TRAVERSAL_WIDE = 5 };
 int rt_scene_set_traversal(rt_scene* scene, int mode);
 /* builds the reference-topology BVHs (shape.rs:94-138, 264-290), flattens them and uploads */
 int rt_scene_commit(rt_scene* scene);
@@ -242,6 +251,17 @@ int rt_scene_get_units(const rt_scene* scene, float* out, size_t n_floats);
  * 0; following the links from there visits the entries in the reference's order. */
 size_t rt_scene_num_walk_units(const rt_scene* scene);
 int rt_scene_get_walk_units(const rt_scene* scene, float* out, size_t n_floats);
+/* host-only scenes: the wide tree RT_TRAVERSAL_WIDE walks (no counterpart in the reference).  A
+ * node is 20 words: 0-2 the origin of its grid (floats); 3 the exponent bytes of the grid step
+ * along x, y, z (step = 2^(e - 127)) and, in bits 24-31, the mask of child slots that hold nodes;
+ * 4 the node slot of child slot 0 (child slot s lives at node slot [4] + s); 5 the index of the
+ * node's first primitive record; 6 the mask of child slots that hold primitives (their records
+ * follow each other in slot order); 8-19 the children's planes, one byte per slot, two words per
+ * plane in the order min x, min y, min z, max x, max y, max z (plane = origin + byte * step).  A
+ * primitive record is 16 floats: the first 12 floats of the primitive's entry in
+ * rt_scene_get_entries().  Node slot 0 is the root; depth = levels of nodes. */
+int rt_scene_wide_info(const rt_scene* scene, size_t* n_nodes, size_t* n_prims, uint32_t* depth);
+int rt_scene_get_wide(const rt_scene* scene, uint32_t* nodes, size_t n_node_words, float* prims, size_t n_prim_floats);
 
 /* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */
 int rt_trace(rt_scene* scene, const rt_ray* rays, size_t n, float t_min, float t_max, rt_hit* out);

@@ -27,12 +27,12 @@ ASSET_DIR = os.path.join(_HERE, "assets")
 MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
-TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSAL_OCTANT = 0, 1, 2, 3, 4
+TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSAL_OCTANT, TRAVERSAL_WIDE = 0, 1, 2, 3, 4, 5
 BUILD_REFERENCE, BUILD_SAH = 0, 1
 CACHE_OFF, CACHE_STORED, CACHE_LOADED, CACHE_STORE_FAILED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
-FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill")
+FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill", "wide")
 TRACE_STATIC_MAX_RAYS = 4194304
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 
@@ -114,6 +114,8 @@ def _load():
         "rt_scene_get_units": (i32, [vp, vp, sz]),
         "rt_scene_num_walk_units": (sz, [vp]),
         "rt_scene_get_walk_units": (i32, [vp, vp, sz]),
+        "rt_scene_wide_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]),
+        "rt_scene_get_wide": (i32, [vp, vp, sz, vp, sz]),
         "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
         "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
         "rt_trace_device_static": (i32, [vp, vp, sz, f32, f32, vp, vp]),
@@ -163,7 +165,7 @@ ABI_SYMBOLS = [
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
     "rt_scene_set_traversal", "rt_set_default_cache_dir", "rt_scene_set_cache_dir", "rt_scene_cache_state", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
-    "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_trace",
+    "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_scene_wide_info", "rt_scene_get_wide", "rt_trace",
     "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
 HOST_SYMBOLS = [
@@ -349,6 +351,15 @@ class Scene:
         out = np.zeros((lib.rt_scene_num_walk_units(self.h), 4), dtype=np.float32)
         _check(lib.rt_scene_get_walk_units(self.h, _ptr(out), out.size))
         return out
+
+    def wide(self):
+        """The wide tree of a host-only scene: (nodes (n, 20) uint32, primitive records (m, 16) float32, depth)."""
+        n_nodes, n_prims, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
+        _check(lib.rt_scene_wide_info(self.h, C.byref(n_nodes), C.byref(n_prims), C.byref(depth)))
+        nodes = np.zeros((n_nodes.value, 20), dtype=np.uint32)
+        prims = np.zeros((n_prims.value, 16), dtype=np.float32)
+        _check(lib.rt_scene_get_wide(self.h, _ptr(nodes), nodes.size, _ptr(prims) if prims.size else None, prims.size))
+        return nodes, prims, depth.value
 
     def trace(self, rays, t_min=0.001, t_max=np.inf):
         rays = np.ascontiguousarray(rays, dtype=ray_dt)

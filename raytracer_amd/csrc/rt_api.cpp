@@ -147,6 +147,8 @@ struct rt_scene {
     int cache_state = RT_CACHE_OFF;
     FlatScene flat;
     DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats, d_xforms;
+    DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
+    WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
     DevScene dev{};
     std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
 };
@@ -451,6 +453,26 @@ static int apply_traversal(rt_scene* s, int mode) {
         }
         s->dev.units_oct = s->d_units_oct.p;
     }
+    if (mode == RT_TRAVERSAL_WIDE && s->ctx) {
+        if (!s->d_wide_nodes.p) {  // first use: the wide tree, collapsed from the device's entry array
+            int rc = set_device(s->ctx);
+            if (rc) return rc;
+            std::vector<float> entries((size_t)s->dev.n_entries * ENTRY_FLOATS);
+            HIP_TRY(hipMemcpy(entries.data(), s->d_entries.p, entries.size() * 4, hipMemcpyDeviceToHost));
+            WideScene w;
+            const std::string err = build_wide_scene(entries.data(), s->dev.n_entries, w);
+            if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
+            entries.clear(); entries.shrink_to_fit();
+            s->wide.depth = w.depth;
+            HIP_TRY(s->d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
+            HIP_TRY(hipMemcpy(s->d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(s->d_wide_nodes.ensure(w.nodes.size() * 4));
+            HIP_TRY(hipMemcpy(s->d_wide_nodes.p, w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
+        }
+        s->dev.wide_nodes = s->d_wide_nodes.p;
+        s->dev.wide_prims = s->d_wide_prims.p;
+        s->dev.wide_stack = std::max(1u, s->wide.depth);
+    }
     {   // experiment knobs, read whenever the kernel form is (re)chosen.  RT_PRIM_WAIT: lanes that must
         // wait at primitives before their routine runs (best of {1 .. 64} measured on the sphere and OBJ
         // scenes, from memory and out of LDS alike: 8; 2 .. 12 lie within 3 %).  RT_REFILL: idle lanes
@@ -462,6 +484,7 @@ static int apply_traversal(rt_scene* s, int mode) {
     }
     s->dev.octant = mode == RT_TRAVERSAL_OCTANT ? 1u : 0u;
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
+    s->dev.wide = mode == RT_TRAVERSAL_WIDE && s->ctx ? 1u : 0u;
     s->auto_tuned = false;
     s->dev.refill = s->env_refill;
     s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
@@ -525,7 +548,7 @@ int rt_scene_cache_state(const rt_scene* s) { return s ? s->cache_state : RT_CAC
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     RT_GUARD_BEGIN
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_traversal: NULL scene");
-    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_OCTANT) return fail(RT_ERR_INVALID, "unknown traversal mode");
+    if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_WIDE) return fail(RT_ERR_INVALID, "unknown traversal mode");
     if (s->committed) {
         int rc = apply_traversal(s, mode);
         if (rc) return rc;
@@ -680,6 +703,43 @@ int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
     return RT_OK;
 }
 
+// the wide tree of a committed host-only scene, collapsed from its entries on the first call
+static int host_wide(const rt_scene* cs) {
+    rt_scene* s = const_cast<rt_scene*>(cs);
+    if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "the wide tree can be inspected on a committed host-only scene");
+    if (!s->flat.xforms.empty()) return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
+    if (s->wide.nodes.empty()) {
+        const std::string err = build_wide_scene(s->flat.entries.data(), s->flat.n_entries(), s->wide);
+        if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
+    }
+    return RT_OK;
+}
+
+int rt_scene_wide_info(const rt_scene* s, size_t* n_nodes, size_t* n_prims, uint32_t* depth) {
+    RT_GUARD_BEGIN
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_wide_info: NULL scene");
+    int rc = host_wide(s);
+    if (rc) return rc;
+    if (n_nodes) *n_nodes = s->wide.n_nodes();
+    if (n_prims) *n_prims = s->wide.n_prims();
+    if (depth) *depth = s->wide.depth;
+    return RT_OK;
+    RT_GUARD_END("rt_scene_wide_info")
+}
+
+int rt_scene_get_wide(const rt_scene* s, uint32_t* nodes, size_t n_node_words, float* prims, size_t n_prim_floats) {
+    RT_GUARD_BEGIN
+    if (!s || !nodes || (!prims && n_prim_floats)) return fail(RT_ERR_INVALID, "rt_scene_get_wide: NULL argument");
+    int rc = host_wide(s);
+    if (rc) return rc;
+    if (n_node_words != s->wide.nodes.size() || n_prim_floats != s->wide.prims.size())
+        return fail(RT_ERR_INVALID, "rt_scene_get_wide: size mismatch");
+    std::memcpy(nodes, s->wide.nodes.data(), n_node_words * 4);
+    if (n_prim_floats) std::memcpy(prims, s->wide.prims.data(), n_prim_floats * 4);
+    return RT_OK;
+    RT_GUARD_END("rt_scene_get_wide")
+}
+
 size_t rt_scene_num_walk_units(const rt_scene* s) { return s ? s->dev.n_walk : 0; }
 
 int rt_scene_get_walk_units(const rt_scene* s, float* out, size_t n_floats) {
@@ -821,7 +881,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     // when it is traced with the sweep or out of LDS: two kernels in flight hide each other's drain
     // (1024^2 x 64 spp Cornell box +24 %, world1 at 16 spp +13 %).  Not the walk from memory: its
     // refilled form lives on long segments (cornell_box.obj at 256 spp: -30 % when cut up).
-    if (s->dev.sweep || (s->dev.lds_walk && !s->dev.octant && !s->dev.ordered)) {
+    if (s->dev.sweep || (s->dev.lds_walk && !s->dev.octant && !s->dev.ordered && !s->dev.wide)) {
         const char* e = std::getenv("RT_SPLIT_MI");        // experiments: the threshold in Mi paths (0: never)
         const size_t split_mi = e ? (size_t)std::max(0, std::atoi(e)) : (size_t)RT_SPLIT_MI;
         if (!p->max_paths_in_flight && split_mi && n_tiles * 64 * (size_t)n_samples >= (split_mi << 20))
@@ -851,14 +911,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     struct Form { uint32_t sweep, refill, prim_wait; };
     auto form_target = [&](const DevScene& d) -> uint32_t {
         if (d.sweep) return ctx->wave_target_sweep;
-        if (std::getenv("RT_WAVE_TARGET") || d.ordered || staged) return ctx->wave_target;
+        if (std::getenv("RT_WAVE_TARGET") || d.ordered || d.wide || staged) return ctx->wave_target;
         if (d.lds_walk && !d.octant) return ctx->wave_target / 4;   // 8-wave workgroups even out less finely
         return d.refill ? ctx->wave_target / 2 : ctx->wave_target;   // refill wants long segments
     };
     auto seg_len_for = [&](size_t n_slots, uint32_t target) -> uint32_t {
         return std::max<uint32_t>(64u, (uint32_t)(((n_slots + target - 1) / target + 63u) / 64u * 64u));
     };
-    if (!s->auto_tuned && !staged && !s->dev.ordered && !std::getenv("RT_NO_AUTOTUNE")) {
+    if (!s->auto_tuned && !staged && !s->dev.ordered && !s->dev.wide && !std::getenv("RT_NO_AUTOTUNE")) {
         std::vector<Form> forms;
         const uint32_t wait_mem = s->env_prim_wait ? s->env_prim_wait : 8u, wait_refill = s->env_prim_wait ? s->env_prim_wait : 16u;
         if (s->traversal == RT_TRAVERSAL_AUTO && s->dev.sweep && s->dev.lds_walk)
@@ -1130,7 +1190,8 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         stats->ms_shade = ms_by_kind[1];
         stats->n_devices = 1;
         const DevScene& d = s->dev;            // the form the launches above took
-        stats->kernel_form = d.ordered ? RT_FORM_ORDERED
+        stats->kernel_form = d.wide ? RT_FORM_WIDE
+                             : d.ordered ? RT_FORM_ORDERED
                              : d.octant ? (d.refill && !staged ? RT_FORM_OCTANT_REFILL : RT_FORM_OCTANT)
                              : d.sweep ? RT_FORM_SWEEP
                              : staged ? RT_FORM_WALK

@@ -503,6 +503,107 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
     best_prim = r.best_prim;
 }
 
+// Wide walk (opt-in; not the reference's visiting order, and not its trees): the scene's entries
+// collapsed into nodes of up to eight children whose boxes the node holds itself, 8 bits per plane on
+// a grid local to the node (80 bytes; the layout is described beside WIDE_NODE_WORDS).  One visit
+// fetches a node, tests its eight boxes, queues the primitives among the children that were hit and
+// descends into the nearest node among them; the others wait on the lane's stack as ONE word per
+// level (node slot of the group << 8 | children still to visit).  The primitive tests are the
+// reference's own (tri_step / sphere_step), so t is theirs.
+// Box test: a child's planes are origin + byte * 2^e, and t = (plane - o) * inv_d is taken in the
+// fused form byte * (2^e * inv_d) + (origin - o) * inv_d, one FMA per plane.  The builder keeps a
+// grid step of slack on every side of the true box, which covers the form's rounding.  NaNs (a
+// zero direction component against a plane the origin lies on) drop out of max / min, which only
+// ever widens the interval.  A NaN best_t (shape.rs:25-36 accepts a sphere hit whose discriminant
+// overflowed) leaves every box open in the reference; here it counts as +inf, which opens every
+// box the ray passes at all -- no primitive outside those can be hit.
+// Order: the builder puts a child in the slot whose diagonal matches its offset from the node's
+// centre, so for a ray whose direction is positive along the axes in rb the children lie roughly in
+// descending (slot ^ rb); the mask of hit children is permuted to that order once and the highest
+// bit is taken first.
+__device__ __forceinline__ float plane_byte(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xFFu); }
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+                                                 uint32_t prim_wait, uint32_t* stack, uint32_t lane, bool valid,
+                                                 float ox, float oy, float oz, float dx, float dy, float dz,
+                                                 float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
+    LaneRay r;
+    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    const uint32_t rb = (dx >= 0.0f ? 1u : 0u) | (dy >= 0.0f ? 2u : 0u) | (dz >= 0.0f ? 4u : 0u);
+    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+    // the group in hand: node slot of its child slot 0 << 8 | children still to visit, child slot s
+    // at bit s ^ rb.  The root is "child rb ^ rb = 0 of the group at slot 0".
+    uint32_t G = valid ? 1u << rb : 0u;
+    uint32_t sp = 0;                           // stack slots in use
+    uint32_t pend = 0, pbase = 0, lmask = 0;   // primitives of the last node still to test (by slot), their records
+    for (;;) {
+        const bool at_prim = pend != 0u;
+        const bool at_node = !at_prim && ((G & 0xFFu) != 0u || sp != 0u);
+        const unsigned long long mb = __ballot(at_node), mp = __ballot(at_prim);
+        if ((mb | mp) == 0ull) break;
+        if (at_node) {
+            if (COUNT) cnt.box++;
+            if ((G & 0xFFu) == 0u) { sp--; G = stack[sp * 64u + lane]; }
+            const uint32_t p = 31u - (uint32_t)__clz((int)(G & 0xFFu));
+            G ^= 1u << p;
+            const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * 5u;
+            const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
+            const float sx = u2f((q0.w & 0xFFu) << 23) * r.ix;
+            const float sy = u2f((q0.w >> 8 & 0xFFu) << 23) * r.iy;
+            const float sz = u2f((q0.w >> 16 & 0xFFu) << 23) * r.iz;
+            const float bx = (u2f(q0.x) - r.ox) * r.ix, by = (u2f(q0.y) - r.oy) * r.iy, bz = (u2f(q0.z) - r.oz) * r.iz;
+            // the planes the ray meets first and last along each axis, slots 0-3 and 4-7
+            const uint32_t nx0 = nx ? q3.z : q2.x, nx1 = nx ? q3.w : q2.y, fx0 = nx ? q2.x : q3.z, fx1 = nx ? q2.y : q3.w;
+            const uint32_t ny0 = ny ? q4.x : q2.z, ny1 = ny ? q4.y : q2.w, fy0 = ny ? q2.z : q4.x, fy1 = ny ? q2.w : q4.y;
+            const uint32_t nz0 = nz ? q4.z : q3.x, nz1 = nz ? q4.w : q3.y, fz0 = nz ? q3.x : q4.z, fz1 = nz ? q3.y : q4.w;
+            const float bt = r.best_t == r.best_t ? r.best_t : __builtin_inff();
+            uint32_t hm = 0;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int j = s & 3;
+                const float tnx = __builtin_fmaf(plane_byte(s < 4 ? nx0 : nx1, j), sx, bx);
+                const float tny = __builtin_fmaf(plane_byte(s < 4 ? ny0 : ny1, j), sy, by);
+                const float tnz = __builtin_fmaf(plane_byte(s < 4 ? nz0 : nz1, j), sz, bz);
+                const float tfx = __builtin_fmaf(plane_byte(s < 4 ? fx0 : fx1, j), sx, bx);
+                const float tfy = __builtin_fmaf(plane_byte(s < 4 ? fy0 : fy1, j), sy, by);
+                const float tfz = __builtin_fmaf(plane_byte(s < 4 ? fz0 : fz1, j), sz, bz);
+                const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), t_min);
+                const float tf = fminf(fminf(fminf(tfx, tfy), tfz), bt);
+                hm |= tn <= tf ? 1u << s : 0u;
+            }
+            const uint32_t imask = q0.w >> 24;
+            lmask = q1.z;
+            pbase = q1.y;
+            pend = hm & lmask;
+            uint32_t ih = hm & imask;          // to visiting order: bit s -> bit s ^ rb
+            ih = (rb & 1u) ? ((ih & 0x55u) << 1 | (ih >> 1 & 0x55u)) : ih;
+            ih = (rb & 2u) ? ((ih & 0x33u) << 2 | (ih >> 2 & 0x33u)) : ih;
+            ih = (rb & 4u) ? ((ih & 0x0Fu) << 4 | (ih >> 4 & 0x0Fu)) : ih;
+            if (ih != 0u) {
+                if ((G & 0xFFu) != 0u) { stack[sp * 64u + lane] = G; sp++; }
+                G = q1.x << 8 | ih;
+            }
+        }
+        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
+            if (at_prim) {
+                const uint32_t s = (uint32_t)__ffs((int)pend) - 1u;
+                pend &= pend - 1u;
+                const float4* pp = prims + (size_t)(pbase + (uint32_t)__popc(lmask & ((1u << s) - 1u))) * 4u;
+                const float4 a = pp[0], b = pp[1], c = pp[2];
+                if ((f2u(a.w) >> TAG_SHIFT) == TAG_TRI) {
+                    if (COUNT) cnt.tri++;
+                    tri_step(a, b, c, r, t_min);
+                } else {
+                    if (COUNT) cnt.sph++;
+                    sphere_step(a, b, r, t_min);
+                }
+            }
+        }
+    }
+    best_t = r.best_t;
+    best_prim = r.best_prim;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Closest hit, wave-synchronous form for small scenes.  Skip links only point forward, so a
 // wave can sweep the entry array ONCE in order: entry e is fetched with scalar loads into
@@ -728,7 +829,8 @@ extern __shared__ uint32_t lds_stack[];
 // SWEEP: 0 = per-lane walk, 1 = wave sweep (scene without spheres), 2 = wave sweep (any scene),
 //        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
-//        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes
+//        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
+//        11 = stack walk of the wide tree (10 is the split walk, k_path only)
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -774,6 +876,10 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 9)
                 closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+            else if (SWEEP == 11)
+                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait,
+                                        lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid,
+                                        ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
@@ -1148,6 +1254,10 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 9)
                 closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 11)
+                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait,
+                                        lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
+                                        b.x, b.y, b.z, t_min, t, prim, cnt);
             else
                 closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
@@ -1487,7 +1597,7 @@ static inline int check_launch() { return hipGetLastError() == hipSuccess ? 0 : 
 
 // Which unit holds the kernel a scene is traced with: the wave sweep lives in the default unit,
 // every per-lane walk in the unit built without SLP vectorisation.
-static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant && !sc.n_xforms; }
+static inline bool uses_sweep_kernels(const DevScene& sc) { return sc.sweep && !sc.ordered && !sc.octant && !sc.wide && !sc.n_xforms; }
 int launch_trace_api_walk(const LaunchCfg&, const DevScene&, const void* d_rays, size_t n, float t_min, float t_max,
                           void* d_hits, Totals* d_counts, bool count, uint32_t grid);
 int launch_trace_walk(const LaunchCfg&, const DevScene&, const BatchGeom&, const RenderBuffers&, uint32_t depth,
@@ -1527,11 +1637,16 @@ static inline PathBuffers path_buffers(const RenderBuffers& rb) {
 }
 
 #ifdef RT_HAS_WALK
+// LDS of the walks that keep a per-lane stack: one word per lane and slot
+static inline size_t stack_bytes(const DevScene& sc, uint32_t waves) {
+    return (size_t)waves * (sc.wide ? sc.wide_stack : sc.ordered ? sc.stack_depth : 0u) * 64u * sizeof(uint32_t);
+}
 int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* d_rays, size_t n, float t_min,
                           float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid) {
     hipStream_t st = (hipStream_t)cfg.stream;
-    const size_t lds = sc.ordered ? (size_t)(RT_BLOCK / 64) * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
-    if (sc.n_xforms) { if (count) RT_TRACE_API(true, 9); else RT_TRACE_API(false, 9); }
+    const size_t lds = stack_bytes(sc, RT_BLOCK / 64);
+    if (sc.wide) { if (count) RT_TRACE_API(true, 11); else RT_TRACE_API(false, 11); }
+    else if (sc.n_xforms) { if (count) RT_TRACE_API(true, 9); else RT_TRACE_API(false, 9); }
     else if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
     else if (sc.ordered) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
@@ -1542,11 +1657,12 @@ int launch_trace_walk(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom&
                       uint32_t depth, bool last_depth, float t_min, float sky_intensity, bool count) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const uint32_t* segcnt = rb.segcnt + (size_t)depth * g.n_seg;
-    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+    const size_t lds = stack_bytes(sc, RT_WPB);
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.n_xforms) { if (count) RT_TRACE(true, 9); else RT_TRACE(false, 9); }
+    if (sc.wide) { if (count) RT_TRACE(true, 11); else RT_TRACE(false, 11); }
+    else if (sc.n_xforms) { if (count) RT_TRACE(true, 9); else RT_TRACE(false, 9); }
     else if (sc.octant) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
     else if (sc.ordered) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
@@ -1557,10 +1673,11 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
                      const RenderBuffers& rb, uint32_t max_bounces, float t_min, float sky_intensity) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const PathBuffers pb = path_buffers(rb);
-    const size_t lds = sc.ordered ? (size_t)RT_WPB * sc.stack_depth * 64u * sizeof(uint32_t) : 0;
+    const size_t lds = stack_bytes(sc, RT_WPB);
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
+    if (sc.wide) { RT_PATH(11); return check_launch(); }
     if (sc.n_xforms) { RT_PATH(9); return check_launch(); }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;

@@ -135,6 +135,30 @@ bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& f
 void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint32_t>& out);   // units as 32-bit words
 // (the copies carry the explicit links of FlatScene::walk -- child, next -- each in its own pre-order)
 
+// The wide tree of the opt-in RT_TRAVERSAL_WIDE walk (rt_wide.cpp): nodes of up to eight children
+// whose boxes the node stores itself, quantised to 8 bits per plane.  One node = 20 words (80 bytes):
+//   0-2   origin of the node's grid (float)
+//   3     exponent bytes of the grid step along x, y, z (step = 2^(e - 127)) | mask of the slots that hold nodes << 24
+//   4     node slot of child slot 0 (the child in slot s lives at node slot [4] + s)
+//   5     index of the node's first primitive record (those of its primitive slots follow in slot order)
+//   6     mask of the slots that hold primitives
+//   8-19  planes, one byte per slot: min x, min y, min z, max x, max y, max z (two words each);
+//         plane = origin + byte * step
+// One primitive record = 16 floats: the first three float4 of the primitive's entry.
+constexpr uint32_t WIDE_NODE_WORDS = 20;
+constexpr uint32_t WIDE_PRIM_FLOATS = 16;
+constexpr uint32_t WIDE_MAX_DEPTH = 60;        // stack slots per lane the walk may need (one per level)
+struct WideScene {
+    std::vector<uint32_t> nodes;
+    std::vector<float> prims;
+    uint32_t depth = 0;                        // levels of nodes
+    size_t n_nodes() const { return nodes.size() / WIDE_NODE_WORDS; }
+    size_t n_prims() const { return prims.size() / WIDE_PRIM_FLOATS; }
+};
+// collapses the pre-order entry array (without transformed meshes) into a wide tree; returns an
+// empty string on success
+std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out);
+
 // ---------------------------------------------------------------------------------------------
 // Device side
 // ---------------------------------------------------------------------------------------------
@@ -165,6 +189,10 @@ struct DevScene {
     uint32_t octant;          // 1: every ray walks the copy of its direction octant (near child first, no stack)
     uint32_t split_top;       // > 0: the fused kernel keeps the first split_top units of `walk` in LDS (split walk)
     uint32_t deep_wait;       // split walk: lanes that must wait for a unit from memory before the wave fetches for them
+    const void* wide_nodes;   // uint4[5 * node slots]: the wide tree (RT_TRAVERSAL_WIDE)
+    const void* wide_prims;   // float4[4 * primitives of the wide tree]
+    uint32_t wide;            // 1: stack walk of the wide tree, nearer children first (not the reference's visiting order)
+    uint32_t wide_stack;      // stack slots per lane (the wide tree's depth)
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

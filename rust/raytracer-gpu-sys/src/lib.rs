@@ -19,6 +19,7 @@ pub const RT_TRAVERSAL_PER_LANE: c_int = 1;
 pub const RT_TRAVERSAL_SWEEP: c_int = 2;
 pub const RT_TRAVERSAL_ORDERED: c_int = 3;
 pub const RT_TRAVERSAL_OCTANT: c_int = 4;
+pub const RT_TRAVERSAL_WIDE: c_int = 5;
 pub const RT_BUILD_REFERENCE: c_int = 0;
 pub const RT_BUILD_SAH: c_int = 1;
 pub const RT_CACHE_OFF: c_int = 0;
@@ -37,6 +38,7 @@ pub const RT_FORM_WALK_LDS_REFILL: u32 = 4;
 pub const RT_FORM_ORDERED: u32 = 5;
 pub const RT_FORM_OCTANT: u32 = 6;
 pub const RT_FORM_OCTANT_REFILL: u32 = 7;
+pub const RT_FORM_WIDE: u32 = 8;
 pub const RT_TRACE_STATIC_MAX_RAYS: u32 = 4194304;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
@@ -106,6 +108,9 @@ extern "C" {
     pub fn rt_scene_get_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
     pub fn rt_scene_num_walk_units(scene: *const rt_scene) -> usize;
     pub fn rt_scene_get_walk_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_scene_wide_info(scene: *const rt_scene, n_nodes: *mut usize, n_prims: *mut usize, depth: *mut u32) -> c_int;
+    pub fn rt_scene_get_wide(scene: *const rt_scene, nodes: *mut u32, n_node_words: usize, prims: *mut f32,
+                             n_prim_floats: usize) -> c_int;
 
     pub fn rt_trace(scene: *mut rt_scene, rays: *const rt_ray, n: usize, t_min: f32, t_max: f32, out: *mut rt_hit) -> c_int;
     pub fn rt_trace_device(scene: *mut rt_scene, d_rays: *const c_void, n: usize, t_min: f32, t_max: f32,

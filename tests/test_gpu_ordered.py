@@ -1,8 +1,10 @@
 """The opt-in near-child-first walks (RT_TRAVERSAL_ORDERED: per-lane stack; RT_TRAVERSAL_OCTANT: one
-pre-ordered copy of the trees per direction octant, no stack) against the oracle.
+pre-ordered copy of the trees per direction octant, no stack; RT_TRAVERSAL_WIDE: the trees collapsed
+into eight-child nodes with 8-bit boxes, per-lane stack) against the oracle.
 
-Both run the reference's box and primitive tests on the reference's trees but visits the nearer
-child first, so theirs is not the reference's visiting order.  The closest hit must still be the
+The first two run the reference's box and primitive tests on the reference's trees but visit the nearer
+child first, so theirs is not the reference's visiting order; the wide walk runs the reference's
+primitive tests behind boxes of its own that enclose the reference's.  The closest hit must still be the
 oracle's: same hit/miss, bit-identical t, and the same primitive unless two primitives tie in t.
 t, the hit point and hit/miss must match on every ray.  The primitive may differ where two
 primitives tie in t, which real scenes do produce (a ray through the shared diagonal of a wall's
@@ -17,9 +19,9 @@ from helpers import asset, mirror, random_rays, random_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["ordered", "octant"])
+@pytest.fixture(params=["ordered", "octant", "wide"])
 def walk(request, rt):
-    return {"ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT}[request.param]
+    return {"ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[request.param]
 
 
 def _ordered_vs_oracle(rt, sc, walk, rays, want, t_min=0.001, t_max=np.inf, same_prim=True):
@@ -150,3 +152,47 @@ def test_fewer_visits_and_same_image(rt, ob, ctx, monkeypatch):
         assert st8["rays_traced"] == st["rays_traced"]
         assert np.array_equal(img8.view(np.uint32), img.view(np.uint32))
     monkeypatch.delenv("RT_REFILL", raising=False)
+
+
+def test_wide_walk_adversarial_rays_and_frames(rt, ob, ctx):
+    """The wide walk on rays that stress the box test's comparison forms (zero and negative-zero
+    direction components, axis-aligned rays, origins on integer planes, tiny and huge directions:
+    its fused box test meets 0 * inf and inf - inf there and must stay conservative), on both build
+    modes; its visit counts; and its frames against the reference-order walk's (same RNG keys, so a
+    pixel differs only where a tie went the other way)."""
+    from helpers import adversarial_rays, product_camera
+    mats, objects, _ = random_scene(ob, 9, n_spheres=37, n_meshes=3, tris_per_mesh=200)
+    osc = ob.Scene.from_description(mats, objects, ob.ROOT_BVH)
+    rays = np.concatenate([adversarial_rays(rt, 3, 120000, 10.0), random_rays(ob, 4, 60000, -12.0, 12.0)])
+    want, _ = osc.trace(rays)
+    for build in (rt.BUILD_REFERENCE, rt.BUILD_SAH):
+        sc = rt.Scene(ctx, mats, objects, ob.ROOT_BVH, build=build)
+        _ordered_vs_oracle(rt, sc, rt.TRAVERSAL_WIDE, rays, want)
+    import torch
+    for name in ("cornell_box.obj", "cornell_box_plane.obj"):
+        osc = ob.Scene.cornell_box(asset(name))
+        sc = mirror(rt, ctx, osc)
+        rays = osc.record_rays(64, 64, 2, 8, cap=60000)
+        d_rays = torch.from_numpy(rays.view(np.float32).reshape(-1, 6)).cuda()
+        d_hits = torch.zeros(len(rays) * 10, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+        ref_counts = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
+        sc.set_traversal(rt.TRAVERSAL_WIDE)
+        counts = sc.trace_device(d_rays.data_ptr(), len(rays), d_hits.data_ptr(), count=True)
+        print(f"{name}: per ray {ref_counts[0] / len(rays):.1f} box + {ref_counts[1] / len(rays):.1f} triangle tests in "
+              f"reference order, {counts[0] / len(rays):.1f} wide nodes + {counts[1] / len(rays):.1f} triangle tests")
+        assert counts[0] * 2 < ref_counts[0]
+        cam = product_camera(rt, osc, 96, 96)
+        p = rt.Scene.params(96, 96, 16, 8, osc.sky)
+        sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+        ref, st_ref = sc.render(cam, p)
+        sc.set_traversal(rt.TRAVERSAL_WIDE)
+        img, st = sc.render(cam, p)
+        assert st["kernel_form"] == rt.FORM_NAMES.index("wide")
+        staged, st_s = sc.render(cam, rt.Scene.params(96, 96, 16, 8, osc.sky, flags=rt.RENDER_STAGED))
+        assert st_s["rays_traced"] == st["rays_traced"] and np.array_equal(staged.view(np.uint32), img.view(np.uint32))
+        assert abs(st["rays_traced"] - st_ref["rays_traced"]) <= 1e-4 * st_ref["rays_traced"]
+        differing = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).mean()
+        print(f"{name}: pixels that differ between the wide walk and the reference order: {differing:.2e}")
+        assert differing <= 1e-3

@@ -70,10 +70,10 @@ def _same_up_to_ties(rt, got, want, label):
     assert ties <= 1e-4 * len(want)
 
 
-@pytest.mark.parametrize("walk", ["ordered", "octant"])
+@pytest.mark.parametrize("walk", ["ordered", "octant", "wide"])
 def test_soup_near_first_walks(rt, ob, ctx, soup, walk):
     world, osc, rays, want = soup
-    world.scene.set_traversal(rt.TRAVERSAL_ORDERED if walk == "ordered" else rt.TRAVERSAL_OCTANT)
+    world.scene.set_traversal({"ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[walk])
     try:
         _same_up_to_ties(rt, world.scene.trace(rays), want, f"{walk} walk")
     finally:
@@ -87,7 +87,8 @@ def test_soup_sah_tree(rt, ob, ctx, soup):
         world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
     finally:
         rt.set_default_build(rt.BUILD_REFERENCE)
-    for mode, label in ((rt.TRAVERSAL_PER_LANE, "SAH tree, per-lane walk"), (rt.TRAVERSAL_OCTANT, "SAH tree, octant walk")):
+    for mode, label in ((rt.TRAVERSAL_PER_LANE, "SAH tree, per-lane walk"), (rt.TRAVERSAL_OCTANT, "SAH tree, octant walk"),
+                        (rt.TRAVERSAL_WIDE, "SAH tree collapsed to eight-child nodes, wide walk")):
         world.scene.set_traversal(mode)
         _same_up_to_ties(rt, world.scene.trace(rays), want, label)
     world.close()

@@ -1,0 +1,208 @@
+"""The wide tree of the opt-in RT_TRAVERSAL_WIDE walk, on host-only scenes (no GPU).
+
+The tree has no counterpart in the reference (its trees are binary, shape.rs:87-139, 185-192): it
+is the scene's flattened entries collapsed into nodes of up to eight children with 8-bit boxes.
+Checked here: the structure (every primitive of the entry array is a leaf exactly once, every
+child's quantised box encloses what lies beneath it with a grid step to spare, the recorded depth),
+and a Python mirror of the device loop (same stack discipline, same fused box test, the
+reference's primitive tests in f32) against the oracle's closest hits: hit / miss and t bit for
+bit, the primitive unless two tie in t."""
+import numpy as np
+import pytest
+
+from helpers import asset, random_mesh, random_rays, random_scene
+from test_host_layer import F, _prim_test
+
+
+def _planes(node):
+    """(origin[3], step[3], lo[8, 3], hi[8, 3]) of a node in float64 (grid points are exact there)."""
+    origin = node[0:3].view(np.float32).astype(np.float64)
+    e = np.array([node[3] & 0xFF, node[3] >> 8 & 0xFF, node[3] >> 16 & 0xFF], dtype=np.int64)
+    step = np.ldexp(1.0, e - 127)
+    q = node[8:20].view(np.uint8).reshape(6, 8).astype(np.float64)     # plane p, slot s
+    lo = origin[None, :] + q[0:3].T * step[None, :]
+    hi = origin[None, :] + q[3:6].T * step[None, :]
+    return origin, step, lo, hi
+
+
+def _prim_box(rec):
+    tag = int(rec.view(np.uint32)[3]) >> 30
+    if tag == 1:
+        p = np.stack([rec[0:3], rec[0:3] + rec[4:7], rec[0:3] + rec[8:11]]).astype(np.float64)
+        return p.min(axis=0), p.max(axis=0)
+    c, r = rec[0:3].astype(np.float64), abs(float(rec[4]))
+    return c - r, c + r
+
+
+def _check_structure(nodes, prims, depth, entries):
+    ent_u = entries.view(np.uint32)
+    tags = ent_u[:, 3] >> 30
+    want_ids = sorted(int(x) for x in ent_u[tags != 0, 7])
+    got_ids = sorted(int(x) for x in prims.view(np.uint32)[:, 7])
+    assert got_ids == want_ids                       # every primitive once
+    seen_prims = np.zeros(len(prims), dtype=bool)
+    max_level = 0
+
+    def visit(slot, level):
+        """returns the (lo, hi) of everything beneath the node"""
+        nonlocal max_level
+        max_level = max(max_level, level)
+        node = nodes[slot]
+        imask, lmask = int(node[3]) >> 24, int(node[6])
+        assert imask & lmask == 0
+        _, step, qlo, qhi = _planes(node)
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        rank = 0
+        for s in range(8):
+            if lmask >> s & 1:
+                idx = int(node[5]) + rank
+                rank += 1
+                assert not seen_prims[idx]
+                seen_prims[idx] = True
+                lo, hi = _prim_box(prims[idx])
+            elif imask >> s & 1:
+                lo, hi = visit(int(node[4]) + s, level + 1)
+            else:
+                continue
+            assert (qlo[s] <= lo - 0.5 * step).all() and (qhi[s] >= hi + 0.5 * step).all()
+            lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+        return lo_all, hi_all
+
+    if len(prims):
+        visit(0, 1)
+    assert seen_prims.all()
+    assert max_level == depth or (len(prims) == 0 and depth == 1)
+
+
+def _walk_wide(nodes, prims, o, d, t_min, t_max):
+    """Mirror of closest_hit_wide: returns (prim, t, node visits, primitive tests)."""
+    pu = prims.view(np.uint32)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        o, d = [F(x) for x in o], [F(x) for x in d]
+        inv = [F(1.0) / d[k] for k in range(3)]
+        rb = sum(1 << k for k in range(3) if d[k] >= 0)
+        best_t, best = F(t_max), 0xFFFFFFFF
+        G, stack = 1 << rb, []
+        n_nodes = n_prims = 0
+        while (G & 0xFF) or stack:
+            if not (G & 0xFF):
+                G = stack.pop()
+            p = (G & 0xFF).bit_length() - 1
+            G ^= 1 << p
+            node = nodes[(G >> 8) + (p ^ rb)]
+            n_nodes += 1
+            origin = node[0:3].view(np.float32)
+            e = [int(node[3]) >> (8 * k) & 0xFF for k in range(3)]
+            imask, lmask = int(node[3]) >> 24, int(node[6])
+            q = node[8:20].view(np.uint8).reshape(6, 8)
+            sx = [F(np.ldexp(F(1.0), e[k] - 127) * inv[k]) for k in range(3)]
+            bx = [F(F(origin[k] - o[k]) * inv[k]) for k in range(3)]
+            bt = best_t if best_t == best_t else F(np.inf)
+            hm = 0
+            for s in range(8):
+                tn, tf = F(t_min), bt
+                for k in range(3):
+                    near, far = (q[3 + k, s], q[k, s]) if inv[k] < 0 else (q[k, s], q[3 + k, s])
+                    a = F(np.float64(near) * np.float64(sx[k]) + np.float64(bx[k]))
+                    b = F(np.float64(far) * np.float64(sx[k]) + np.float64(bx[k]))
+                    tn = a if a > tn else tn         # (a NaN drops out, as in fmaxf / fminf)
+                    tf = b if b < tf else tf
+                if tn <= tf:
+                    hm |= 1 << s
+            pend = hm & lmask
+            while pend:
+                s = (pend & -pend).bit_length() - 1
+                pend &= pend - 1
+                idx = int(node[5]) + bin(lmask & ((1 << s) - 1)).count("1")
+                n_prims += 1
+                best_t, best = _prim_test(prims[idx], int(pu[idx, 3]) >> 30, int(pu[idx, 7]), o, d, t_min, best_t, best)
+            ih = 0
+            for s in range(8):
+                if (hm & imask) >> s & 1:
+                    ih |= 1 << (s ^ rb)
+            if ih:
+                if G & 0xFF:
+                    stack.append(G)
+                G = int(node[4]) << 8 | ih
+    return best, best_t, n_nodes, n_prims
+
+
+def _compare(nodes, prims, rays, want, t_min=0.001, t_max=np.inf):
+    ties = 0
+    for k in range(len(rays)):
+        prim, t, _, _ = _walk_wide(nodes, prims, rays["o"][k], rays["d"][k], F(t_min), F(t_max))
+        wp = int(want["prim_id"][k])
+        assert (prim == 0xFFFFFFFF) == (wp == 0xFFFFFFFF), k
+        if wp != 0xFFFFFFFF and not np.isnan(want["t"][k]):
+            assert F(t).view(np.uint32) == want["t"][k].view(np.uint32), k
+            ties += prim != wp
+    return ties
+
+
+@pytest.mark.parametrize("root,build", [(0, 0), (2, 0), (0, 1)])
+def test_wide_tree_structure_and_hits(rt, ob, root, build):
+    mats, objects, _ = random_scene(ob, 21 + root, n_spheres=23, n_meshes=3, tris_per_mesh=70, extent=6.0)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root, build=build)
+    nodes, prims, depth = sc.wide()
+    _check_structure(nodes, prims, depth, sc.entries())
+    rays = random_rays(ob, 7, 300, -7.0, 7.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 50
+    assert _compare(nodes, prims, rays, want) <= 1
+    want, _ = osc.trace(rays, 0.05, 2.0, nthreads=1)
+    assert _compare(nodes, prims, rays, want, 0.05, 2.0) <= 1
+
+
+def test_wide_tree_degenerate_scenes(rt, ob):
+    mats, _, _ = random_scene(ob, 5)
+    rng = np.random.default_rng(0)
+    one = np.zeros(1, dtype=ob.sphere_dt)
+    one["r"] = 1.0
+    many = np.zeros(30, dtype=ob.sphere_dt)            # a list of thirty objects: more than eight children
+    many["c"] = rng.uniform(-3, 3, (30, 3)).astype(np.float32)
+    many["r"] = 0.4
+    cases = [([("spheres", one)], ob.ROOT_BVH), ([("spheres", one)], ob.ROOT_SINGLE), ([], ob.ROOT_BVH),
+             ([("mesh", random_mesh(ob, rng, 0))], ob.ROOT_SINGLE), ([("spheres", many)], ob.ROOT_LIST)]
+    for n in (1, 2, 3, 9):
+        cases.append(([("mesh", random_mesh(ob, rng, n, extent=2.0))], ob.ROOT_SINGLE))
+    flat = np.zeros(12, dtype=ob.triangle_dt)          # coplanar, axis-aligned: boxes without thickness
+    flat["p"][:, :, :2] = rng.uniform(-2, 2, (12, 3, 2)).astype(np.float32)
+    flat["n0"][:, 2] = 1.0
+    cases.append(([("mesh", flat)], ob.ROOT_SINGLE))
+    rays = random_rays(ob, 1, 120, -3.0, 3.0)
+    for objects, root in cases:
+        osc = ob.Scene.from_description(mats, objects, root)
+        sc = rt.Scene(None, mats, objects, root)
+        nodes, prims, depth = sc.wide()
+        _check_structure(nodes, prims, depth, sc.entries())
+        want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+        assert _compare(nodes, prims, rays, want) == 0
+
+
+def test_wide_tree_of_the_obj_scenes(rt, ob):
+    """thing.obj and the plane Cornell box: structure, depth, and fewer node visits than the binary
+    walk makes box tests."""
+    from test_host_layer import _walk
+    for osc in (ob.Scene.world2(asset("thing.obj"), 1), ob.Scene.cornell_box(asset("cornell_box_plane.obj"))):
+        sc = rt.Scene(None, osc.materials(), osc.objects(), osc.root_kind)
+        nodes, prims, depth = sc.wide()
+        ent = sc.entries()
+        _check_structure(nodes, prims, depth, ent)
+        rays = osc.record_rays(24, 24, 1, 4, cap=150)
+        want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+        assert _compare(nodes, prims, rays, want) <= 2
+        wide_nodes = sum(_walk_wide(nodes, prims, r["o"], r["d"], F(0.001), F(np.inf))[2] for r in rays[:60])
+        boxes = sum(_walk(ent, r["o"], r["d"], F(0.001), F(np.inf), count=True)[2] for r in rays[:60])
+        print(f"node visits {wide_nodes} against {boxes} box tests on 60 rays, depth {depth}, {len(nodes)} node slots")
+        assert wide_nodes * 2 < boxes
+
+
+def test_wide_tree_refuses_transformed_meshes(rt, ob):
+    mats, _, _ = random_scene(ob, 5)
+    rng = np.random.default_rng(1)
+    m = np.eye(4, dtype=np.float32)
+    m[3, 0] = 2.0
+    sc = rt.Scene(None, mats, [("mesh", random_mesh(ob, rng, 5), m.reshape(-1))], ob.ROOT_SINGLE)
+    with pytest.raises(rt.RtError):
+        sc.wide()
