@@ -43,7 +43,7 @@ WORKLOADS = {
     "soup_10m_4k_256": ("soup", 3840, 2160, 256, 16),
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_workloads.json")
-KERNEL_SOURCES = ("rt_device.hip", "rt_device_walk.hip", "rt_internal.hpp", "rt_api.cpp", "rt_build.cpp", "Makefile")
+KERNEL_SOURCES = ("rt_device.hip", "rt_device_walk.hip", "rt_internal.hpp", "rt_api.cpp", "rt_build.cpp", "rt_wide.cpp", "Makefile")
 
 
 def make_world(ctx, kind):
@@ -423,7 +423,10 @@ def main():
                        "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3),
                        "reduce_ms_per_step": round(ms_reduce / args.steps, 3),
                        "accum_sum": float(accum.double().sum().item())},
-            "roofline": roofline(args.workload if headline or args.spp else None, args.build, form_name, total_rays / elapsed_max,
+            # (the opt-in walks have counter records of their own, keyed <workload>/<build>/<traversal>)
+            "roofline": roofline(args.workload if headline or args.spp else None,
+                                 args.build + (f"/{args.traversal}" if args.traversal in ("wide", "ordered", "octant") else ""),
+                                 form_name, total_rays / elapsed_max,
                                  world, algo_gbs, bytes_per_ray,
                                  {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)}, extra),
         }

@@ -111,7 +111,7 @@ typedef struct {
  * so two runs may differ here (never in the frame) */
 enum { RT_FORM_SWEEP = 0, RT_FORM_WALK = 1, RT_FORM_WALK_LDS = 2, RT_FORM_WALK_REFILL = 3,
        RT_FORM_WALK_LDS_REFILL = 4, RT_FORM_ORDERED = 5, RT_FORM_OCTANT = 6, RT_FORM_OCTANT_REFILL = 7,
-       RT_FORM_WIDE = 8 };
+       RT_FORM_WIDE = 8, RT_FORM_WIDE_REFILL = 9 };
 
 typedef struct {
     uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */

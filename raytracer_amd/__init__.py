@@ -32,7 +32,7 @@ BUILD_REFERENCE, BUILD_SAH = 0, 1
 CACHE_OFF, CACHE_STORED, CACHE_LOADED, CACHE_STORE_FAILED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
-FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill", "wide")
+FORM_NAMES = ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill", "ordered", "octant", "octant_refill", "wide", "wide_refill")
 TRACE_STATIC_MAX_RAYS = 4194304
 DEFAULT_SEED = 0x9E3779B97F4A7C15
 

@@ -503,6 +503,7 @@ static int apply_traversal(rt_scene* s, int mode) {
             s->auto_tuned = true;
         }
     }
+    if (s->dev.wide && !std::getenv("RT_REFILL")) s->dev.refill = 16;      // the wide walk refills idle lanes by default
     if (s->dev.n_xforms != 0) {                // one form follows the transform markers: the plain walk from memory
         s->dev.sweep = 0;
         s->dev.refill = 0;
@@ -911,7 +912,8 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     struct Form { uint32_t sweep, refill, prim_wait; };
     auto form_target = [&](const DevScene& d) -> uint32_t {
         if (d.sweep) return ctx->wave_target_sweep;
-        if (std::getenv("RT_WAVE_TARGET") || d.ordered || d.wide || staged) return ctx->wave_target;
+        if (std::getenv("RT_WAVE_TARGET") || d.ordered || staged) return ctx->wave_target;
+        if (d.wide) return d.refill ? ctx->wave_target / 2 : ctx->wave_target;
         if (d.lds_walk && !d.octant) return ctx->wave_target / 4;   // 8-wave workgroups even out less finely
         return d.refill ? ctx->wave_target / 2 : ctx->wave_target;   // refill wants long segments
     };
@@ -1190,7 +1192,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         stats->ms_shade = ms_by_kind[1];
         stats->n_devices = 1;
         const DevScene& d = s->dev;            // the form the launches above took
-        stats->kernel_form = d.wide ? RT_FORM_WIDE
+        stats->kernel_form = d.wide ? (d.refill && !staged ? RT_FORM_WIDE_REFILL : RT_FORM_WIDE)
                              : d.ordered ? RT_FORM_ORDERED
                              : d.octant ? (d.refill && !staged ? RT_FORM_OCTANT_REFILL : RT_FORM_OCTANT)
                              : d.sweep ? RT_FORM_SWEEP

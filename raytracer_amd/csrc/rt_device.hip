@@ -522,6 +522,100 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
 // descending (slot ^ rb); the mask of hit children is permuted to that order once and the highest
 // bit is taken first.
 __device__ __forceinline__ float plane_byte(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xFFu); }
+// A lane's place in the wide tree.
+struct WideLane {
+    uint32_t G;                // the group in hand: node slot of its child slot 0 << 8 | children still to visit, child slot s at bit s ^ rb
+    uint32_t sp;               // stack slots in use
+    uint32_t pend;             // primitives of the last node still to test, by child slot
+    uint32_t pbase, lmask;     // that node's first primitive record and its mask of primitive slots
+    uint32_t rb;               // axes along which the ray's direction is positive
+};
+__device__ __forceinline__ void wide_lane_init(WideLane& w, bool valid, float dx, float dy, float dz) {
+    w.rb = (dx >= 0.0f ? 1u : 0u) | (dy >= 0.0f ? 2u : 0u) | (dz >= 0.0f ? 4u : 0u);
+    w.G = valid ? 1u << w.rb : 0u;             // the root is "child rb ^ rb = 0 of the group at node slot 0"
+    w.sp = 0;
+    w.pend = 0; w.pbase = 0; w.lmask = 0;
+}
+__device__ __forceinline__ bool wide_live(const WideLane& w) { return w.pend != 0u || (w.G & 0xFFu) != 0u || w.sp != 0u; }
+// One trip of the wide walk for the whole wave: lanes that need a node take the nearest child still
+// to visit (from the group in hand, else from the stack), fetch it and test its eight boxes; lanes
+// with primitives of their last node in hand test one of them, once prim_wait lanes wait (or no lane
+// needs a node).  `stack` is this wave's LDS region, slot s of a lane at stack[s * 64 + lane].
+// Returns false when no lane has anything left.
+template <bool COUNT>
+__device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+                                          uint32_t prim_wait, uint32_t* stack, uint32_t lane, LaneRay& r,
+                                          WideLane& w, float t_min, Counts& cnt) {
+    const bool at_prim = w.pend != 0u;
+    const bool at_node = !at_prim && ((w.G & 0xFFu) != 0u || w.sp != 0u);
+    const unsigned long long mb = __ballot(at_node), mp = __ballot(at_prim);
+    if ((mb | mp) == 0ull) return false;
+    RT_UTIL_TRIP(cnt);
+    if (at_node) {
+        if (COUNT) cnt.box++;
+        uint32_t G = w.G;
+        if ((G & 0xFFu) == 0u) { w.sp--; G = stack[w.sp * 64u + lane]; }
+        const uint32_t rb = w.rb;
+        const uint32_t p = 31u - (uint32_t)__clz((int)(G & 0xFFu));
+        G ^= 1u << p;
+        const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * 5u;
+        const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
+        const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
+        const float sx = u2f((q0.w & 0xFFu) << 23) * r.ix;
+        const float sy = u2f((q0.w >> 8 & 0xFFu) << 23) * r.iy;
+        const float sz = u2f((q0.w >> 16 & 0xFFu) << 23) * r.iz;
+        const float bx = (u2f(q0.x) - r.ox) * r.ix, by = (u2f(q0.y) - r.oy) * r.iy, bz = (u2f(q0.z) - r.oz) * r.iz;
+        // the planes the ray meets first and last along each axis, slots 0-3 and 4-7
+        const uint32_t nx0 = nx ? q3.z : q2.x, nx1 = nx ? q3.w : q2.y, fx0 = nx ? q2.x : q3.z, fx1 = nx ? q2.y : q3.w;
+        const uint32_t ny0 = ny ? q4.x : q2.z, ny1 = ny ? q4.y : q2.w, fy0 = ny ? q2.z : q4.x, fy1 = ny ? q2.w : q4.y;
+        const uint32_t nz0 = nz ? q4.z : q3.x, nz1 = nz ? q4.w : q3.y, fz0 = nz ? q3.x : q4.z, fz1 = nz ? q3.y : q4.w;
+        const float bt = r.best_t == r.best_t ? r.best_t : __builtin_inff();
+        uint32_t hm = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            const int j = s & 3;
+            const float tnx = __builtin_fmaf(plane_byte(s < 4 ? nx0 : nx1, j), sx, bx);
+            const float tny = __builtin_fmaf(plane_byte(s < 4 ? ny0 : ny1, j), sy, by);
+            const float tnz = __builtin_fmaf(plane_byte(s < 4 ? nz0 : nz1, j), sz, bz);
+            const float tfx = __builtin_fmaf(plane_byte(s < 4 ? fx0 : fx1, j), sx, bx);
+            const float tfy = __builtin_fmaf(plane_byte(s < 4 ? fy0 : fy1, j), sy, by);
+            const float tfz = __builtin_fmaf(plane_byte(s < 4 ? fz0 : fz1, j), sz, bz);
+            const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), t_min);
+            const float tf = fminf(fminf(fminf(tfx, tfy), tfz), bt);
+            hm |= tn <= tf ? 1u << s : 0u;
+        }
+        const uint32_t imask = q0.w >> 24;
+        w.lmask = q1.z;
+        w.pbase = q1.y;
+        w.pend = hm & w.lmask;
+        uint32_t ih = hm & imask;              // to visiting order: bit s -> bit s ^ rb
+        ih = (rb & 1u) ? ((ih & 0x55u) << 1 | (ih >> 1 & 0x55u)) : ih;
+        ih = (rb & 2u) ? ((ih & 0x33u) << 2 | (ih >> 2 & 0x33u)) : ih;
+        ih = (rb & 4u) ? ((ih & 0x0Fu) << 4 | (ih >> 4 & 0x0Fu)) : ih;
+        if (ih != 0u) {
+            if ((G & 0xFFu) != 0u) { stack[w.sp * 64u + lane] = G; w.sp++; }
+            G = q1.x << 8 | ih;
+        }
+        w.G = G;
+    }
+    if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
+        if (at_prim) {
+            const uint32_t s = (uint32_t)__ffs((int)w.pend) - 1u;
+            w.pend &= w.pend - 1u;
+            const float4* pp = prims + (size_t)(w.pbase + (uint32_t)__popc(w.lmask & ((1u << s) - 1u))) * 4u;
+            const float4 a = pp[0], b = pp[1], c = pp[2];
+            if ((f2u(a.w) >> TAG_SHIFT) == TAG_TRI) {
+                if (COUNT) cnt.tri++;
+                tri_step(a, b, c, r, t_min);
+            } else {
+                if (COUNT) cnt.sph++;
+                sphere_step(a, b, r, t_min);
+            }
+        }
+    }
+    return true;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
                                                  uint32_t prim_wait, uint32_t* stack, uint32_t lane, bool valid,
@@ -529,77 +623,9 @@ __device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes
                                                  float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
-    const uint32_t rb = (dx >= 0.0f ? 1u : 0u) | (dy >= 0.0f ? 2u : 0u) | (dz >= 0.0f ? 4u : 0u);
-    const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
-    // the group in hand: node slot of its child slot 0 << 8 | children still to visit, child slot s
-    // at bit s ^ rb.  The root is "child rb ^ rb = 0 of the group at slot 0".
-    uint32_t G = valid ? 1u << rb : 0u;
-    uint32_t sp = 0;                           // stack slots in use
-    uint32_t pend = 0, pbase = 0, lmask = 0;   // primitives of the last node still to test (by slot), their records
-    for (;;) {
-        const bool at_prim = pend != 0u;
-        const bool at_node = !at_prim && ((G & 0xFFu) != 0u || sp != 0u);
-        const unsigned long long mb = __ballot(at_node), mp = __ballot(at_prim);
-        if ((mb | mp) == 0ull) break;
-        if (at_node) {
-            if (COUNT) cnt.box++;
-            if ((G & 0xFFu) == 0u) { sp--; G = stack[sp * 64u + lane]; }
-            const uint32_t p = 31u - (uint32_t)__clz((int)(G & 0xFFu));
-            G ^= 1u << p;
-            const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * 5u;
-            const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
-            const float sx = u2f((q0.w & 0xFFu) << 23) * r.ix;
-            const float sy = u2f((q0.w >> 8 & 0xFFu) << 23) * r.iy;
-            const float sz = u2f((q0.w >> 16 & 0xFFu) << 23) * r.iz;
-            const float bx = (u2f(q0.x) - r.ox) * r.ix, by = (u2f(q0.y) - r.oy) * r.iy, bz = (u2f(q0.z) - r.oz) * r.iz;
-            // the planes the ray meets first and last along each axis, slots 0-3 and 4-7
-            const uint32_t nx0 = nx ? q3.z : q2.x, nx1 = nx ? q3.w : q2.y, fx0 = nx ? q2.x : q3.z, fx1 = nx ? q2.y : q3.w;
-            const uint32_t ny0 = ny ? q4.x : q2.z, ny1 = ny ? q4.y : q2.w, fy0 = ny ? q2.z : q4.x, fy1 = ny ? q2.w : q4.y;
-            const uint32_t nz0 = nz ? q4.z : q3.x, nz1 = nz ? q4.w : q3.y, fz0 = nz ? q3.x : q4.z, fz1 = nz ? q3.y : q4.w;
-            const float bt = r.best_t == r.best_t ? r.best_t : __builtin_inff();
-            uint32_t hm = 0;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const int j = s & 3;
-                const float tnx = __builtin_fmaf(plane_byte(s < 4 ? nx0 : nx1, j), sx, bx);
-                const float tny = __builtin_fmaf(plane_byte(s < 4 ? ny0 : ny1, j), sy, by);
-                const float tnz = __builtin_fmaf(plane_byte(s < 4 ? nz0 : nz1, j), sz, bz);
-                const float tfx = __builtin_fmaf(plane_byte(s < 4 ? fx0 : fx1, j), sx, bx);
-                const float tfy = __builtin_fmaf(plane_byte(s < 4 ? fy0 : fy1, j), sy, by);
-                const float tfz = __builtin_fmaf(plane_byte(s < 4 ? fz0 : fz1, j), sz, bz);
-                const float tn = fmaxf(fmaxf(fmaxf(tnx, tny), tnz), t_min);
-                const float tf = fminf(fminf(fminf(tfx, tfy), tfz), bt);
-                hm |= tn <= tf ? 1u << s : 0u;
-            }
-            const uint32_t imask = q0.w >> 24;
-            lmask = q1.z;
-            pbase = q1.y;
-            pend = hm & lmask;
-            uint32_t ih = hm & imask;          // to visiting order: bit s -> bit s ^ rb
-            ih = (rb & 1u) ? ((ih & 0x55u) << 1 | (ih >> 1 & 0x55u)) : ih;
-            ih = (rb & 2u) ? ((ih & 0x33u) << 2 | (ih >> 2 & 0x33u)) : ih;
-            ih = (rb & 4u) ? ((ih & 0x0Fu) << 4 | (ih >> 4 & 0x0Fu)) : ih;
-            if (ih != 0u) {
-                if ((G & 0xFFu) != 0u) { stack[sp * 64u + lane] = G; sp++; }
-                G = q1.x << 8 | ih;
-            }
-        }
-        if (mb == 0ull || (uint32_t)__popcll(mp) >= prim_wait) {
-            if (at_prim) {
-                const uint32_t s = (uint32_t)__ffs((int)pend) - 1u;
-                pend &= pend - 1u;
-                const float4* pp = prims + (size_t)(pbase + (uint32_t)__popc(lmask & ((1u << s) - 1u))) * 4u;
-                const float4 a = pp[0], b = pp[1], c = pp[2];
-                if ((f2u(a.w) >> TAG_SHIFT) == TAG_TRI) {
-                    if (COUNT) cnt.tri++;
-                    tri_step(a, b, c, r, t_min);
-                } else {
-                    if (COUNT) cnt.sph++;
-                    sphere_step(a, b, r, t_min);
-                }
-            }
-        }
-    }
+    WideLane w;
+    wide_lane_init(w, valid, dx, dy, dz);
+    while (wide_trip<COUNT>(nodes, prims, prim_wait, stack, lane, r, w, t_min, cnt)) {}
     best_t = r.best_t;
     best_prim = r.best_prim;
 }
@@ -830,7 +856,7 @@ extern __shared__ uint32_t lds_stack[];
 //        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
 //        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
-//        11 = stack walk of the wide tree (10 is the split walk, k_path only)
+//        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only)
 template <bool COUNT, int SWEEP>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -1177,6 +1203,64 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     }
 }
 
+// The wide walk over a whole segment with idle lanes refilled, as walk_segment does for the per-lane
+// walk: the wide walk is bound by instruction issue, and a wave that runs until its longest ray ends
+// issues most of its instructions for a few lanes.
+template <bool COUNT>
+__device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+                                             uint32_t prim_wait, uint32_t refill_min, uint32_t* stack, uint32_t lane,
+                                             const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
+                                             const float4* __restrict__ A, const float4* __restrict__ B,
+                                             const float4* __restrict__ C, uint2* __restrict__ hits,
+                                             uint32_t* __restrict__ q0, uint32_t* __restrict__ q1,
+                                             uint32_t* __restrict__ q2, float4* __restrict__ Lbuf, uint32_t base,
+                                             uint32_t n, uint32_t last_depth, float t_min, float sky_intensity,
+                                             uint32_t& n0, uint32_t& n1, uint32_t& n2, Counts& cnt) {
+    LaneRay r;
+    lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
+    WideLane w;
+    wide_lane_init(w, false, 1.0f, 1.0f, 1.0f);
+    uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
+    bool has_ray = false;
+    uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
+    for (;;) {
+        const bool live = wide_live(w);
+        const unsigned long long m_live = __ballot(live);
+        const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
+        if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
+            uint32_t kind = 7u;
+            if (has_ray && !live) {
+                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t, r.best_prim,
+                                  last_depth, sky_intensity);
+                has_ray = false;
+            }
+            uint32_t pos;
+            pos = wave_append(kind == 0u, n0);
+            if (kind == 0u) q0[base + pos] = ray_i;
+            pos = wave_append(kind == 1u, n1);
+            if (kind == 1u) q1[base + pos] = ray_i;
+            pos = wave_append(kind == 2u, n2);
+            if (kind == 2u) q2[base + pos] = ray_i;
+            if (next >= n) {
+                if (m_live == 0ull) break;
+            } else {
+                const uint32_t j = next + lane_prefix(~m_live);
+                if (!live && j < n) {
+                    ray_i = base + j;
+                    const float4 ra = A[ray_i], rb = B[ray_i];
+                    lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
+                    wide_lane_init(w, true, rb.x, rb.y, rb.z);
+                    slot = f2u(ra.w);
+                    has_ray = true;
+                }
+                next = min(n, next + n_idle);
+                continue;
+            }
+        }
+        wide_trip<COUNT>(nodes, prims, prim_wait, stack, lane, r, w, t_min, cnt);
+    }
+}
+
 // Closest hit for the n live rays of the segment at `base`: terminates paths (sky, emitter, depth
 // cap) or records the hit and queues the ray under its material kind; n0 / n1 / n2 return the
 // queue lengths.  Whole wave, converged.
@@ -1231,6 +1315,10 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                          SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, mats, sc.prim_meta,
                                          A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
                                          n1, n2, cnt);
+    } else if (SWEEP == 12) {
+        wide_segment<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
+                            lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
+                            q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 8) {
         walk_segment<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
                                   mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
@@ -1677,7 +1765,7 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.wide) { RT_PATH(11); return check_launch(); }
+    if (sc.wide) { if (sc.refill) RT_PATH(12); else RT_PATH(11); return check_launch(); }
     if (sc.n_xforms) { RT_PATH(9); return check_launch(); }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;

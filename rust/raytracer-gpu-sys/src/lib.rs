@@ -39,6 +39,7 @@ pub const RT_FORM_ORDERED: u32 = 5;
 pub const RT_FORM_OCTANT: u32 = 6;
 pub const RT_FORM_OCTANT_REFILL: u32 = 7;
 pub const RT_FORM_WIDE: u32 = 8;
+pub const RT_FORM_WIDE_REFILL: u32 = 9;
 pub const RT_TRACE_STATIC_MAX_RAYS: u32 = 4194304;
 
 #[repr(C)] #[derive(Clone, Copy, Default)]

@@ -154,7 +154,7 @@ def test_fewer_visits_and_same_image(rt, ob, ctx, monkeypatch):
     monkeypatch.delenv("RT_REFILL", raising=False)
 
 
-def test_wide_walk_adversarial_rays_and_frames(rt, ob, ctx):
+def test_wide_walk_adversarial_rays_and_frames(rt, ob, ctx, monkeypatch):
     """The wide walk on rays that stress the box test's comparison forms (zero and negative-zero
     direction components, axis-aligned rays, origins on integer planes, tiny and huge directions:
     its fused box test meets 0 * inf and inf - inf there and must stay conservative), on both build
@@ -189,9 +189,15 @@ def test_wide_walk_adversarial_rays_and_frames(rt, ob, ctx):
         ref, st_ref = sc.render(cam, p)
         sc.set_traversal(rt.TRAVERSAL_WIDE)
         img, st = sc.render(cam, p)
-        assert st["kernel_form"] == rt.FORM_NAMES.index("wide")
+        assert rt.FORM_NAMES[st["kernel_form"]] == "wide_refill"
         staged, st_s = sc.render(cam, rt.Scene.params(96, 96, 16, 8, osc.sky, flags=rt.RENDER_STAGED))
         assert st_s["rays_traced"] == st["rays_traced"] and np.array_equal(staged.view(np.uint32), img.view(np.uint32))
+        monkeypatch.setenv("RT_REFILL", "0")   # (read when the traversal is set): the fused kernel without refilling
+        sc.set_traversal(rt.TRAVERSAL_WIDE)
+        plain, st_p = sc.render(cam, p)
+        monkeypatch.delenv("RT_REFILL")
+        assert rt.FORM_NAMES[st_p["kernel_form"]] == "wide"
+        assert st_p["rays_traced"] == st["rays_traced"] and np.array_equal(plain.view(np.uint32), img.view(np.uint32))
         assert abs(st["rays_traced"] - st_ref["rays_traced"]) <= 1e-4 * st_ref["rays_traced"]
         differing = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).mean()
         print(f"{name}: pixels that differ between the wide walk and the reference order: {differing:.2e}")

@@ -2,6 +2,8 @@
 # PMC passes of the per-batch kernel for every benchmark workload (run on the GPU box from the
 # repository root):
 #   bash tools/profile_workloads.sh <out dir> [build] [workload ...]      # build: reference (default) | sah
+# TRAVERSAL=wide (or ordered, octant) in the environment profiles that opt-in walk instead of the
+# form the library picks by itself; its records are keyed <workload>/<build>/<traversal>.
 # Per workload: one unprofiled run to learn which form of the closest-hit loop the first render's
 # timing takes (the profiler serialises kernels, which would tip that timing), then three
 # rocprofv3 --pmc runs with that form pinned (SQ counters; FETCH_SIZE; WRITE_SIZE -- separate runs,
@@ -21,8 +23,8 @@ for wl in $wls; do
         cornell_plane_1024_1k) spp=256;; world1_1080p_256) spp=64;; thing_glass_2048_512) spp=32;;
         cornell_full_512_64) spp=256;; soup_10m_4k_256) spp=8;; *) spp=16;;
     esac
-    name=${wl}_$build
-    timeout -k 10 600 python3 -u bench.py --no-cpu --steps 1 --warmup 1 --workload $wl --spp $spp --build $build > $out/${name}_plain.json 2> $out/${name}_plain.err \
+    name=${wl}_$build${TRAVERSAL:+_$TRAVERSAL}
+    timeout -k 10 600 python3 -u bench.py --no-cpu --steps 1 --warmup 1 --workload $wl --spp $spp --build $build ${TRAVERSAL:+--traversal $TRAVERSAL} > $out/${name}_plain.json 2> $out/${name}_plain.err \
         || { tail -5 $out/${name}_plain.err; exit 1; }
     form=$(python3 -c "import json,sys; print(json.loads(open('$out/${name}_plain.json').read().strip().splitlines()[-1])['config']['kernel_form'])")
     case $form in
@@ -31,6 +33,11 @@ for wl in $wls; do
         walk_lds_refill) pin="--traversal per_lane"; envs="RT_REFILL=16";;
         walk) pin="--traversal per_lane"; envs="RT_REFILL=0";;
         walk_refill) pin="--traversal per_lane"; envs="RT_REFILL=16 RT_PRIM_WAIT=16";;
+        ordered) pin="--traversal $form"; envs="RT_NO_AUTOTUNE=1";;
+        wide) pin="--traversal wide"; envs="RT_REFILL=0";;
+        wide_refill) pin="--traversal wide"; envs="RT_REFILL=16";;
+        octant) pin="--traversal octant"; envs="RT_REFILL=0";;
+        octant_refill) pin="--traversal octant"; envs="RT_REFILL=16 RT_PRIM_WAIT=16";;
         *) echo "unexpected form $form"; exit 1;;
     esac
     for pass in sq f w; do

@@ -65,7 +65,9 @@ def main():
               f"{valu_per_ray:.0f} | {sq['SQ_INSTS_VALU'] / simd_cycles:.3f} | {lanes:.1f} | "
               f"{sq['SQ_WAVE_CYCLES'] * 4 / simd_cycles:.1f} | {sq['SQ_WAIT_ANY'] / sq['SQ_WAVE_CYCLES']:.2f} | {clock:.2f} | "
               f"{vmem_per_ray:.2f} | {ta_busy:.2f} |")
-        records[f"{wl}/{build}"] = {
+        trav = j["config"].get("traversal", "auto")
+        key = f"{wl}/{build}" + (f"/{trav}" if trav in ("wide", "ordered", "octant") else "")
+        records[key] = {
             "form": form, "rays_profiled": rays, "spp_profiled": j["config"]["workload"].split(", ")[1],
             "hbm_bytes_per_ray": round(hbm_per_ray, 2),
             "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
