@@ -259,8 +259,10 @@ int rt_scene_get_walk_units(const rt_scene* scene, float* out, size_t n_floats);
  * follow each other in slot order); 8-19 the children's planes, one byte per slot, two words per
  * plane in the order min x, min y, min z, max x, max y, max z (plane = origin + byte * step).  A
  * primitive record is 16 floats: the first 12 floats of the primitive's entry in
- * rt_scene_get_entries().  Node slot 0 is the root; depth = levels of nodes. */
-int rt_scene_wide_info(const rt_scene* scene, size_t* n_nodes, size_t* n_prims, uint32_t* depth);
+ * rt_scene_get_entries().  Node slot 0 is the root; depth = levels of nodes.  node_words is the
+ * stride of the node array in words: 20, or 32 (the last 12 unused) for trees of more than 32 MB,
+ * which are laid out one node per 128-byte line. */
+int rt_scene_wide_info(const rt_scene* scene, size_t* n_nodes, size_t* n_prims, uint32_t* depth, uint32_t* node_words);
 int rt_scene_get_wide(const rt_scene* scene, uint32_t* nodes, size_t n_node_words, float* prims, size_t n_prim_floats);
 
 /* ---- closest hit: Hittable::hit (shape.rs:7) on a batch -- the hit-parity surface ------ */

@@ -114,7 +114,7 @@ def _load():
         "rt_scene_get_units": (i32, [vp, vp, sz]),
         "rt_scene_num_walk_units": (sz, [vp]),
         "rt_scene_get_walk_units": (i32, [vp, vp, sz]),
-        "rt_scene_wide_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32)]),
+        "rt_scene_wide_info": (i32, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(u32), C.POINTER(u32)]),
         "rt_scene_get_wide": (i32, [vp, vp, sz, vp, sz]),
         "rt_trace": (i32, [vp, vp, sz, f32, f32, vp]),
         "rt_trace_device": (i32, [vp, vp, sz, f32, f32, vp, C.POINTER(C.c_uint64)]),
@@ -354,9 +354,9 @@ class Scene:
 
     def wide(self):
         """The wide tree of a host-only scene: (nodes (n, 20) uint32, primitive records (m, 16) float32, depth)."""
-        n_nodes, n_prims, depth = C.c_size_t(), C.c_size_t(), C.c_uint32()
-        _check(lib.rt_scene_wide_info(self.h, C.byref(n_nodes), C.byref(n_prims), C.byref(depth)))
-        nodes = np.zeros((n_nodes.value, 20), dtype=np.uint32)
+        n_nodes, n_prims, depth, words = C.c_size_t(), C.c_size_t(), C.c_uint32(), C.c_uint32()
+        _check(lib.rt_scene_wide_info(self.h, C.byref(n_nodes), C.byref(n_prims), C.byref(depth), C.byref(words)))
+        nodes = np.zeros((n_nodes.value, words.value), dtype=np.uint32)
         prims = np.zeros((n_prims.value, 16), dtype=np.float32)
         _check(lib.rt_scene_get_wide(self.h, _ptr(nodes), nodes.size, _ptr(prims) if prims.size else None, prims.size))
         return nodes, prims, depth.value

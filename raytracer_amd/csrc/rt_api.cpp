@@ -460,10 +460,16 @@ static int apply_traversal(rt_scene* s, int mode) {
             std::vector<float> entries((size_t)s->dev.n_entries * ENTRY_FLOATS);
             HIP_TRY(hipMemcpy(entries.data(), s->d_entries.p, entries.size() * 4, hipMemcpyDeviceToHost));
             WideScene w;
+            const auto t_begin = std::chrono::steady_clock::now();
             const std::string err = build_wide_scene(entries.data(), s->dev.n_entries, w);
             if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
+            if (std::getenv("RT_BUILD_TIMING"))
+                std::fprintf(stderr, "[rt build] wide tree                    %.3f s (%zu node slots, %zu primitives, %u levels)\n",
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), w.n_nodes(),
+                             w.n_prims(), w.depth);
             entries.clear(); entries.shrink_to_fit();
             s->wide.depth = w.depth;
+            s->wide.node_words = w.node_words;
             HIP_TRY(s->d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
             HIP_TRY(hipMemcpy(s->d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(s->d_wide_nodes.ensure(w.nodes.size() * 4));
@@ -472,6 +478,7 @@ static int apply_traversal(rt_scene* s, int mode) {
         s->dev.wide_nodes = s->d_wide_nodes.p;
         s->dev.wide_prims = s->d_wide_prims.p;
         s->dev.wide_stack = std::max(1u, s->wide.depth);
+        s->dev.wide_stride = s->wide.node_words / 4u;
     }
     {   // experiment knobs, read whenever the kernel form is (re)chosen.  RT_PRIM_WAIT: lanes that must
         // wait at primitives before their routine runs (best of {1 .. 64} measured on the sphere and OBJ
@@ -716,7 +723,7 @@ static int host_wide(const rt_scene* cs) {
     return RT_OK;
 }
 
-int rt_scene_wide_info(const rt_scene* s, size_t* n_nodes, size_t* n_prims, uint32_t* depth) {
+int rt_scene_wide_info(const rt_scene* s, size_t* n_nodes, size_t* n_prims, uint32_t* depth, uint32_t* node_words) {
     RT_GUARD_BEGIN
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_wide_info: NULL scene");
     int rc = host_wide(s);
@@ -724,6 +731,7 @@ int rt_scene_wide_info(const rt_scene* s, size_t* n_nodes, size_t* n_prims, uint
     if (n_nodes) *n_nodes = s->wide.n_nodes();
     if (n_prims) *n_prims = s->wide.n_prims();
     if (depth) *depth = s->wide.depth;
+    if (node_words) *node_words = s->wide.node_words;
     return RT_OK;
     RT_GUARD_END("rt_scene_wide_info")
 }

@@ -543,7 +543,7 @@ __device__ __forceinline__ bool wide_live(const WideLane& w) { return w.pend != 
 // needs a node).  `stack` is this wave's LDS region, slot s of a lane at stack[s * 64 + lane].
 // Returns false when no lane has anything left.
 template <bool COUNT>
-__device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+__device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                           uint32_t prim_wait, uint32_t* stack, uint32_t lane, LaneRay& r,
                                           WideLane& w, float t_min, Counts& cnt) {
     const bool at_prim = w.pend != 0u;
@@ -558,7 +558,7 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, const
         const uint32_t rb = w.rb;
         const uint32_t p = 31u - (uint32_t)__clz((int)(G & 0xFFu));
         G ^= 1u << p;
-        const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * 5u;
+        const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * stride;
         const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
         const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
         const float sx = u2f((q0.w & 0xFFu) << 23) * r.ix;
@@ -617,7 +617,7 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, const
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+__device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                                  uint32_t prim_wait, uint32_t* stack, uint32_t lane, bool valid,
                                                  float ox, float oy, float oz, float dx, float dy, float dz,
                                                  float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
@@ -625,7 +625,7 @@ __device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes
     lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
     WideLane w;
     wide_lane_init(w, valid, dx, dy, dz);
-    while (wide_trip<COUNT>(nodes, prims, prim_wait, stack, lane, r, w, t_min, cnt)) {}
+    while (wide_trip<COUNT>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt)) {}
     best_t = r.best_t;
     best_prim = r.best_prim;
 }
@@ -903,7 +903,7 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             else if (SWEEP == 9)
                 closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 11)
-                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait,
+                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid,
                                         ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
@@ -1207,7 +1207,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
 // walk: the wide walk is bound by instruction issue, and a wave that runs until its longest ray ends
 // issues most of its instructions for a few lanes.
 template <bool COUNT>
-__device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, const float4* __restrict__ prims,
+__device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                              uint32_t prim_wait, uint32_t refill_min, uint32_t* stack, uint32_t lane,
                                              const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
                                              const float4* __restrict__ A, const float4* __restrict__ B,
@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, co
                 continue;
             }
         }
-        wide_trip<COUNT>(nodes, prims, prim_wait, stack, lane, r, w, t_min, cnt);
+        wide_trip<COUNT>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt);
     }
 }
 
@@ -1316,7 +1316,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                          A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
                                          n1, n2, cnt);
     } else if (SWEEP == 12) {
-        wide_segment<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
+        wide_segment<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
                             lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
                             q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 8) {
@@ -1343,7 +1343,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             else if (SWEEP == 9)
                 closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 11)
-                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, (const float4*)sc.wide_prims, sc.prim_wait,
+                closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
                                         b.x, b.y, b.z, t_min, t, prim, cnt);
             else

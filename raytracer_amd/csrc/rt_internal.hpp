@@ -146,13 +146,20 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
 //         plane = origin + byte * step
 // One primitive record = 16 floats: the first three float4 of the primitive's entry.
 constexpr uint32_t WIDE_NODE_WORDS = 20;
+// A node array of more than WIDE_PACKED_MAX_BYTES is stored with one node per 128-byte line (stride
+// WIDE_LINE_WORDS, the last 12 words unused): such a tree is read from HBM, where a node that
+// straddles two lines costs two fetches (10 M-triangle soup: +15 %); smaller trees live in the caches,
+// where the packed array's smaller footprint is worth more.
+constexpr uint32_t WIDE_LINE_WORDS = 32;
+constexpr size_t WIDE_PACKED_MAX_BYTES = (size_t)32 << 20;
 constexpr uint32_t WIDE_PRIM_FLOATS = 16;
 constexpr uint32_t WIDE_MAX_DEPTH = 60;        // stack slots per lane the walk may need (one per level)
 struct WideScene {
     std::vector<uint32_t> nodes;
     std::vector<float> prims;
     uint32_t depth = 0;                        // levels of nodes
-    size_t n_nodes() const { return nodes.size() / WIDE_NODE_WORDS; }
+    uint32_t node_words = WIDE_NODE_WORDS;     // stride of the node array: WIDE_NODE_WORDS or WIDE_LINE_WORDS
+    size_t n_nodes() const { return nodes.size() / node_words; }
     size_t n_prims() const { return prims.size() / WIDE_PRIM_FLOATS; }
 };
 // collapses the pre-order entry array (without transformed meshes) into a wide tree; returns an
@@ -193,6 +200,7 @@ struct DevScene {
     const void* wide_prims;   // float4[4 * primitives of the wide tree]
     uint32_t wide;            // 1: stack walk of the wide tree, nearer children first (not the reference's visiting order)
     uint32_t wide_stack;      // stack slots per lane (the wide tree's depth)
+    uint32_t wide_stride;     // uint4 per node slot: 5 (packed) or 8 (one node per 128-byte line)
 };
 
 // scenes with at most this many entries are traced with the wave-synchronous sweep by default

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -351,6 +352,53 @@ struct WideBuilder {
 
 }  // namespace
 
+// The builder hands every node with node children a block of eight slots, one per child slot, and
+// most blocks stay half empty.  Here the nodes move to new slots so that the blocks overlap: a
+// node's children still live at [4] + child slot, but the base is the lowest one at which the slots
+// its children need are free (first fit, in depth-first order, so a family stays within a few
+// slots and near its parent), and the holes of one family are taken by the next.  The walk does not
+// change; the array shrinks to little more than the nodes there are.
+void compact_nodes(std::vector<uint32_t>& nodes) {
+    const size_t n_old = nodes.size() / WIDE_NODE_WORDS;
+    if (n_old <= 1) return;
+    std::vector<uint32_t> out(WIDE_NODE_WORDS, 0u);
+    std::vector<uint8_t> used(1, 1);           // slot 0: the root
+    size_t low = 1;                            // every slot below is taken
+    std::memcpy(out.data(), nodes.data(), WIDE_NODE_WORDS * 4);
+    std::vector<uint32_t> stack{0u};           // new slots of nodes whose children are still to be placed
+    while (!stack.empty()) {
+        const uint32_t at = stack.back();
+        stack.pop_back();
+        const uint32_t imask = out[(size_t)at * WIDE_NODE_WORDS + 3] >> 24;
+        if (!imask) continue;
+        const uint32_t old_base = out[(size_t)at * WIDE_NODE_WORDS + 4];
+        const int first = __builtin_ctz(imask);
+        // (holes more than a few blocks behind the highest slot in use are given up: the search stays short)
+        const size_t from = std::max(low, used.size() > 64 ? used.size() - 64 : 0);
+        size_t base = from > (size_t)first ? from - (size_t)first : 0;
+        for (;; base++) {
+            bool fits = true;
+            for (int s = first; s < 8 && fits; s++)
+                if ((imask >> s & 1) && base + (size_t)s < used.size() && used[base + (size_t)s]) fits = false;
+            if (fits) break;
+        }
+        if (base + 8 > used.size()) { used.resize(base + 8, 0); out.resize((base + 8) * WIDE_NODE_WORDS, 0u); }
+        out[(size_t)at * WIDE_NODE_WORDS + 4] = (uint32_t)base;
+        for (int s = 7; s >= 0; s--) {         // (pushed in reverse: the child in the lowest slot is placed first)
+            if (!(imask >> s & 1)) continue;
+            used[base + (size_t)s] = 1;
+            std::memcpy(&out[(base + (size_t)s) * WIDE_NODE_WORDS], &nodes[((size_t)old_base + (size_t)s) * WIDE_NODE_WORDS],
+                        WIDE_NODE_WORDS * 4);
+            stack.push_back((uint32_t)(base + (size_t)s));
+        }
+        while (low < used.size() && used[low]) low++;
+    }
+    size_t last = used.size();
+    while (last > 1 && !used[last - 1]) last--;
+    out.resize(last * WIDE_NODE_WORDS);
+    nodes.swap(out);
+}
+
 std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out) {
     out = WideScene();
     WideBuilder b{entries, n_entries};
@@ -363,7 +411,18 @@ std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& 
     A.nodes.assign(WIDE_NODE_WORDS, 0u);
     b.make_node(std::move(top), A, 0, 1, 2);
     if (!A.error.empty()) return A.error;
+    if (!std::getenv("RT_WIDE_SPARSE")) compact_nodes(A.nodes);        // (experiments: the blocks as the builder made them)
     if (A.nodes.size() / WIDE_NODE_WORDS >= (1u << 24)) return "the wide tree has more than 2^24 node slots";
+    const char* force = std::getenv("RT_WIDE_STRIDE");                  // (experiments: 20 or 32 whatever the size)
+    const bool lines = force ? std::atoi(force) == (int)WIDE_LINE_WORDS : A.nodes.size() * 4 > WIDE_PACKED_MAX_BYTES;
+    if (lines) {                               // one node per 128-byte line
+        const size_t n_slots = A.nodes.size() / WIDE_NODE_WORDS;
+        std::vector<uint32_t> wide(n_slots * WIDE_LINE_WORDS, 0u);
+        for (size_t i = 0; i < n_slots; i++)
+            std::memcpy(&wide[i * WIDE_LINE_WORDS], &A.nodes[i * WIDE_NODE_WORDS], WIDE_NODE_WORDS * 4);
+        A.nodes.swap(wide);
+        out.node_words = WIDE_LINE_WORDS;
+    }
     out.nodes.swap(A.nodes);
     out.prims.swap(A.prims);
     out.depth = std::max(1u, A.depth);

@@ -109,7 +109,8 @@ extern "C" {
     pub fn rt_scene_get_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
     pub fn rt_scene_num_walk_units(scene: *const rt_scene) -> usize;
     pub fn rt_scene_get_walk_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
-    pub fn rt_scene_wide_info(scene: *const rt_scene, n_nodes: *mut usize, n_prims: *mut usize, depth: *mut u32) -> c_int;
+    pub fn rt_scene_wide_info(scene: *const rt_scene, n_nodes: *mut usize, n_prims: *mut usize, depth: *mut u32,
+                              node_words: *mut u32) -> c_int;
     pub fn rt_scene_get_wide(scene: *const rt_scene, nodes: *mut u32, n_node_words: usize, prims: *mut f32,
                              n_prim_floats: usize) -> c_int;
 

@@ -41,12 +41,15 @@ def _check_structure(nodes, prims, depth, entries):
     got_ids = sorted(int(x) for x in prims.view(np.uint32)[:, 7])
     assert got_ids == want_ids                       # every primitive once
     seen_prims = np.zeros(len(prims), dtype=bool)
+    seen_nodes = set()                               # (the blocks of child slots overlap: no slot may serve two nodes)
     max_level = 0
 
     def visit(slot, level):
         """returns the (lo, hi) of everything beneath the node"""
         nonlocal max_level
         max_level = max(max_level, level)
+        assert slot not in seen_nodes
+        seen_nodes.add(slot)
         node = nodes[slot]
         imask, lmask = int(node[3]) >> 24, int(node[6])
         assert imask & lmask == 0
@@ -71,6 +74,7 @@ def _check_structure(nodes, prims, depth, entries):
     if len(prims):
         visit(0, 1)
     assert seen_prims.all()
+    assert len(seen_nodes) >= 0.6 * len(nodes) or len(nodes) < 16      # the array is mostly nodes, not holes
     assert max_level == depth or (len(prims) == 0 and depth == 1)
 
 
