@@ -256,7 +256,10 @@ int rt_scene_get_walk_units(const rt_scene* scene, float* out, size_t n_floats);
  * along x, y, z (step = 2^(e - 127)) and, in bits 24-31, the mask of child slots that hold nodes;
  * 4 the node slot of child slot 0 (child slot s lives at node slot [4] + s); 5 the index of the
  * node's first primitive record; 6 the mask of child slots that hold primitives (their records
- * follow each other in slot order); 8-19 the children's planes, one byte per slot, two words per
+ * follow each other in slot order); 7 the mask of child slots whose objects the reference tests
+ * without a box test before them (the objects of a HittableList at the root: entered whatever their
+ * boxes say by rays whose |d|^2 is outside [1e-30, 1e18), where the reference's sphere test overflows
+ * or works on denormals and accepts points that have nothing to do with the sphere's box); 8-19 the children's planes, one byte per slot, two words per
  * plane in the order min x, min y, min z, max x, max y, max z (plane = origin + byte * step).  A
  * primitive record is 16 floats: the first 12 floats of the primitive's entry in
  * rt_scene_get_entries().  Node slot 0 is the root; depth = levels of nodes.  node_words is the

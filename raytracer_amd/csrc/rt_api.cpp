@@ -468,12 +468,22 @@ static int apply_traversal(rt_scene* s, int mode) {
                              std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), w.n_nodes(),
                              w.n_prims(), w.depth);
             entries.clear(); entries.shrink_to_fit();
-            s->wide.depth = w.depth;
-            s->wide.node_words = w.node_words;
-            HIP_TRY(s->d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
-            HIP_TRY(hipMemcpy(s->d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
-            HIP_TRY(s->d_wide_nodes.ensure(w.nodes.size() * 4));
-            HIP_TRY(hipMemcpy(s->d_wide_nodes.p, w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
+            // the tree is built once: the scene's copies on the other GPUs of a multi-GPU context get the same arrays
+            std::vector<rt_scene*> targets{s};
+            for (rt_scene* r : s->replicas)
+                if (!r->d_wide_nodes.p) targets.push_back(r);
+            for (rt_scene* t : targets) {
+                rc = set_device(t->ctx);
+                if (rc) return rc;
+                t->wide.depth = w.depth;
+                t->wide.node_words = w.node_words;
+                HIP_TRY(t->d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
+                HIP_TRY(hipMemcpy(t->d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
+                HIP_TRY(t->d_wide_nodes.ensure(w.nodes.size() * 4));
+                HIP_TRY(hipMemcpy(t->d_wide_nodes.p, w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
+            }
+            rc = set_device(s->ctx);
+            if (rc) return rc;
         }
         s->dev.wide_nodes = s->d_wide_nodes.p;
         s->dev.wide_prims = s->d_wide_prims.p;

@@ -529,10 +529,14 @@ struct WideLane {
     uint32_t pend;             // primitives of the last node still to test, by child slot
     uint32_t pbase, lmask;     // that node's first primitive record and its mask of primitive slots
     uint32_t rb;               // axes along which the ray's direction is positive
+    bool wild;                 // |d|^2 is outside [1e-30, 1e18) or a NaN: the reference's sphere test overflows (and
+                               // accepts) or works on denormals (and accepts points far outside the sphere)
 };
 __device__ __forceinline__ void wide_lane_init(WideLane& w, bool valid, float dx, float dy, float dz) {
     w.rb = (dx >= 0.0f ? 1u : 0u) | (dy >= 0.0f ? 2u : 0u) | (dz >= 0.0f ? 4u : 0u);
     w.G = valid ? 1u << w.rb : 0u;             // the root is "child rb ^ rb = 0 of the group at node slot 0"
+    const float dd = dot3(dx, dy, dz, dx, dy, dz);
+    w.wild = !(dd < 1.0e18f && dd > 1.0e-30f);
     w.sp = 0;
     w.pend = 0; w.pbase = 0; w.lmask = 0;
 }
@@ -584,6 +588,11 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint3
             const float tf = fminf(fminf(fminf(tfx, tfy), tfz), bt);
             hm |= tn <= tf ? 1u << s : 0u;
         }
+        // A ray whose |d|^2 overflows the sphere test (shape.rs:25-36 then accepts the NaN) or is a denormal
+        // (the root then lies anywhere) gets "hits" that have nothing to do with the sphere's box, and the
+        // reference tests the objects of a list at the root without any box: such a ray enters the
+        // children that stand for those objects whatever their boxes say.
+        hm |= w.wild ? q1.w : 0u;
         const uint32_t imask = q0.w >> 24;
         w.lmask = q1.z;
         w.pbase = q1.y;

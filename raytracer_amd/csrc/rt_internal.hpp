@@ -142,6 +142,7 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
 //   4     node slot of child slot 0 (the child in slot s lives at node slot [4] + s)
 //   5     index of the node's first primitive record (those of its primitive slots follow in slot order)
 //   6     mask of the slots that hold primitives
+//   7     mask of the slots whose children the reference reaches without a box test (objects of a list at the root)
 //   8-19  planes, one byte per slot: min x, min y, min z, max x, max y, max z (two words each);
 //         plane = origin + byte * step
 // One primitive record = 16 floats: the first three float4 of the primitive's entry.

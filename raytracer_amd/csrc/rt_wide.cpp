@@ -18,6 +18,15 @@
 // point that rounding puts outside its padded box would be lost, and ties in t may resolve to
 // another primitive.
 //
+// Rays whose direction is so long or so short that the sphere test leaves the range of f32: the
+// reference accepts a sphere whose discriminant overflowed to NaN (shape.rs:25-36) wherever it
+// tests one, with |d|^2 a denormal its root lies anywhere, and it tests the objects of a
+// HittableList at the root without any box before them.  Word 7 of a node marks the children that
+// stand for such objects; when a ray's |d|^2 is outside [1e-30, 1e18) (or NaN) the walk enters
+// them whatever their boxes say, as the reference does.  Other rays keep the culling.  (Primitives
+// under boxes stay behind their own boxes for such rays too: there the reference's result depends
+// on which of its boxes rounding leaves open, which no other tree can repeat.)
+//
 // Child slots and order: a child sits in the slot whose diagonal (bit k of the slot index: the
 // positive side along axis k) matches the offset of its centre from the node's centre best, so a
 // ray whose direction is positive along the axes in `r` meets the children roughly in descending
@@ -67,6 +76,9 @@ struct Item {
     std::shared_ptr<std::vector<Item>> group;
     WBox box;
     size_t span = 1;               // entries beneath (what decides whether a subtree gets a thread)
+    // a primitive the reference tests without any box test before it (an object of a HittableList at
+    // the root, shape.rs:60-74, or the root itself), or a group made up here that holds one
+    bool always = false;
 };
 
 struct WideBuilder {
@@ -150,7 +162,7 @@ struct WideBuilder {
             g.group = std::make_shared<std::vector<Item>>(items.begin() + i, items.begin() + i + m);
             g.box = wempty();
             g.span = 0;
-            for (const Item& it : *g.group) { wgrow(g.box, it.box); g.span += it.span; }
+            for (const Item& it : *g.group) { wgrow(g.box, it.box); g.span += it.span; g.always = g.always || it.always; }
             out.push_back(std::move(g));
         }
         items.swap(out);
@@ -240,9 +252,12 @@ struct WideBuilder {
         std::fill(child_in, child_in + 8, -1);
         for (size_t c = 0; c < nc; c++) child_in[slot_of[c]] = (int)c;
 
-        uint32_t imask = 0, lmask = 0;
+        uint32_t imask = 0, lmask = 0, amask = 0;
         for (int s = 0; s < 8; s++)
-            if (child_in[s] >= 0) (is_prim(items[(size_t)child_in[s]]) ? lmask : imask) |= 1u << s;
+            if (child_in[s] >= 0) {
+                (is_prim(items[(size_t)child_in[s]]) ? lmask : imask) |= 1u << s;
+                if (items[(size_t)child_in[s]].always) amask |= 1u << s;
+            }
         size_t child_base = 0;
         if (imask) {
             child_base = A.nodes.size() / WIDE_NODE_WORDS;
@@ -345,6 +360,7 @@ struct WideBuilder {
         w[4] = imask ? (uint32_t)child_base : 0u;
         w[5] = (uint32_t)prim_base;
         w[6] = lmask;
+        w[7] = amask & (imask | lmask);
         std::memcpy(&A.nodes[at * WIDE_NODE_WORDS], w, sizeof(w));
         return all;
     }
@@ -406,6 +422,7 @@ std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& 
     for (size_t i = 0; i < n_entries; i = b.next_sibling(i)) {
         if (b.tag(i) == TAG_END) return "the wide tree does not take transformed meshes";
         top.push_back(b.entry_item(i));
+        top.back().always = b.tag(i) != TAG_BOX;
     }
     Arena A;
     A.nodes.assign(WIDE_NODE_WORDS, 0u);

@@ -61,6 +61,20 @@ def test_one_process_drives_every_gpu():
         assert many["config"]["accum_sum"] == pytest.approx(one["config"]["accum_sum"], rel=1e-5)
 
 
+def test_wide_walk_on_every_gpu_of_a_context():
+    """The opt-in wide walk through the in-process multi-GPU path: the tree is collapsed once and every
+    worker's copy of the scene gets the same arrays; same rays as one GPU, and both forms of starting N ranks agree."""
+    one = _run(1, extra=["--traversal", "wide"])
+    assert one["config"]["kernel_form"] == "wide_refill"
+    plain = _run(1)
+    assert one["config"]["rays_per_step"] == pytest.approx(plain["config"]["rays_per_step"], rel=1e-4)     # (ties aside)
+    for extra in (["--share-gpus", "--traversal", "wide"], ["--traversal", "wide"]):
+        many = _run(3, extra=extra)
+        assert many["n_gpus"] == 3 and many["config"]["kernel_form"] == "wide_refill"
+        assert many["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+        assert many["config"]["accum_sum"] == pytest.approx(one["config"]["accum_sum"], rel=1e-5)
+
+
 def test_render_multi_against_render_device():
     import numpy as np
     import torch

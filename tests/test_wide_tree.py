@@ -102,7 +102,9 @@ def _walk_wide(nodes, prims, o, d, t_min, t_max):
             sx = [F(np.ldexp(F(1.0), e[k] - 127) * inv[k]) for k in range(3)]
             bx = [F(F(origin[k] - o[k]) * inv[k]) for k in range(3)]
             bt = best_t if best_t == best_t else F(np.inf)
-            hm = 0
+            dd = F(F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2]))
+            wild = not (dd < F(1e18) and dd > F(1e-30))
+            hm = int(node[7]) if wild else 0
             for s in range(8):
                 tn, tf = F(t_min), bt
                 for k in range(3):
@@ -182,6 +184,28 @@ def test_wide_tree_degenerate_scenes(rt, ob):
         _check_structure(nodes, prims, depth, sc.entries())
         want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
         assert _compare(nodes, prims, rays, want) == 0
+
+
+def test_wide_walk_keeps_the_overflowed_sphere_hits_of_a_list_root(rt, ob):
+    """A ray whose |d| is about 1e18 overflows the sphere test's discriminant to NaN, and the reference
+    accepts such a hit (shape.rs:25-36) on every sphere it tests -- the objects of a HittableList at
+    the root are tested without any box before them (shape.rs:60-74).  The wide tree marks those
+    objects (word 7 of a node) and such rays enter them whatever the boxes say: hit / miss as the
+    oracle's.  Under a Bvh root every box test of such a ray fails in the reference too."""
+    from helpers import adversarial_rays
+    for root in (ob.ROOT_LIST, ob.ROOT_BVH):
+        mats, objects, _ = random_scene(ob, 31, n_spheres=19, n_meshes=1, tris_per_mesh=9, extent=6.0)
+        osc = ob.Scene.from_description(mats, objects, root)
+        sc = rt.Scene(None, mats, objects, root)
+        nodes, prims, depth = sc.wide()
+        marked = sum(bin(int(n[7])).count("1") for n in nodes)
+        assert (marked > 0) == (root == ob.ROOT_LIST)
+        rays = adversarial_rays(rt, 5, 1500, 8.0)
+        rays = rays[np.abs(rays["d"]).max(axis=1) > 1e15][:120]
+        assert len(rays) > 50
+        want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+        assert (np.isnan(want["t"]) & (want["prim_id"] != 0xFFFFFFFF)).any() == (root == ob.ROOT_LIST)
+        _compare(nodes, prims, rays, want)
 
 
 def test_wide_tree_of_the_obj_scenes(rt, ob):
