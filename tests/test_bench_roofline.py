@@ -27,7 +27,8 @@ def test_committed_records_are_complete():
             "cornell_full_512_64/reference", "soup_10m_4k_256/reference"} <= set(records)
     for key, rec in records.items():
         assert len(rec["source_hash"]) == 16, key
-        assert rec["form"] in ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill"), key
+        opt_in = key.endswith("/wide")             # records of the opt-in wide walk: <workload>/<build>/wide
+        assert rec["form"] in (("wide", "wide_refill") if opt_in else ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill")), key
         for field in ("hbm_bytes_per_ray", "valu_insts_per_ray", "vmem_insts_per_ray", "ta_busy", "clock_ghz", "mrays_profiled"):
             assert rec[field] > 0, (key, field)
 
@@ -56,3 +57,13 @@ def test_missing_and_mismatched_records_are_said_so():
     assert r["frac"] is None and r["traffic"] is None and "no PMC record" in r["note"]
     r = _roofline("cornell_plane_1024_1k", "reference", "walk_lds", 1e10)     # the record is the sweep's
     assert r["pmc"]["profiled_form"] == "sweep" and "another kernel form" in r["note"]
+
+
+def test_the_wide_walk_has_records_of_its_own():
+    """bench.py --traversal wide looks its counters up under <workload>/<build>/wide: the soup's record
+    there says HBM is the bound of that kernel."""
+    rec = bench.pmc_record("soup_10m_4k_256", "reference/wide")
+    assert rec is not None and rec["form"] == "wide_refill"
+    r = _roofline("soup_10m_4k_256", "reference/wide", "wide_refill", rec["mrays_unprofiled"] * 1e6)
+    assert r["bound"] in ("hbm", "address_unit") and 0.4 < r["frac"] <= 1.0
+    assert rec["hbm_bytes_per_ray"] < 0.5 * bench.pmc_record("soup_10m_4k_256", "reference")["hbm_bytes_per_ray"]
