@@ -43,7 +43,7 @@ WORKLOADS = {
     "soup_10m_4k_256": ("soup", 3840, 2160, 256, 16),
 }
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_workloads.json")
-KERNEL_SOURCES = ("rt_device.hip", "rt_device_walk.hip", "rt_internal.hpp", "rt_api.cpp", "rt_build.cpp", "rt_wide.cpp", "Makefile")
+KERNEL_SOURCES = ("rt_device.hip", "rt_device_walk.hip", "rt_internal.hpp", "rt_api.cpp", "rt_build.cpp", "rt_wide.cpp", "rt_wide_device.hip", "Makefile")
 
 
 def make_world(ctx, kind):
@@ -248,6 +248,8 @@ def main():
                     help="initialise the process group and run the collectives even for one rank")
     ap.add_argument("--max-paths", type=int, default=0)
     ap.add_argument("--traversal", choices=["auto", "per_lane", "sweep", "ordered", "octant", "wide"], default="auto")
+    ap.add_argument("--wide-build", choices=["collapse", "device"], default="collapse",
+                    help="--traversal wide: the tree collapsed on the host from the binary trees, or built on the GPU from the primitives")
     args = ap.parse_args()
 
     # stdout carries the ONE JSON line and nothing else: libraries that write to file descriptor 1 on
@@ -301,6 +303,8 @@ def main():
     else:
         wld = make_world(ctx, kind)
     build_s = time.time() - t0
+    if args.wide_build == "device":
+        wld.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
     wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
                              "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,
                              "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[args.traversal])

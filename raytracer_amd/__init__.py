@@ -29,6 +29,7 @@ MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSAL_OCTANT, TRAVERSAL_WIDE = 0, 1, 2, 3, 4, 5
 BUILD_REFERENCE, BUILD_SAH = 0, 1
+WIDE_BUILD_COLLAPSE, WIDE_BUILD_DEVICE = 0, 1
 CACHE_OFF, CACHE_STORED, CACHE_LOADED, CACHE_STORE_FAILED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
 RENDER_PROFILE, RENDER_COUNT_VISITS, RENDER_STAGED = 1, 2, 4
@@ -101,6 +102,7 @@ def _load():
         "rt_scene_end_group": (i32, [vp]),
         "rt_scene_set_root": (i32, [vp, i32]),
         "rt_scene_set_traversal": (i32, [vp, i32]),
+        "rt_scene_set_wide_build": (i32, [vp, i32]),
         "rt_scene_set_build": (i32, [vp, i32]),
         "rt_set_default_build": (i32, [i32]),
         "rt_set_default_cache_dir": (i32, [C.c_char_p]),
@@ -163,7 +165,7 @@ ABI_SYMBOLS = [
     "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
-    "rt_scene_set_traversal", "rt_set_default_cache_dir", "rt_scene_set_cache_dir", "rt_scene_cache_state", "rt_scene_commit",
+    "rt_scene_set_traversal", "rt_scene_set_wide_build", "rt_set_default_cache_dir", "rt_scene_set_cache_dir", "rt_scene_cache_state", "rt_scene_commit",
     "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
     "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_scene_wide_info", "rt_scene_get_wide", "rt_trace",
     "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
@@ -325,6 +327,10 @@ class Scene:
 
     def set_traversal(self, mode):
         _check(lib.rt_scene_set_traversal(self.h, mode))
+
+    def set_wide_build(self, where):
+        """WIDE_BUILD_COLLAPSE (host, from the binary trees) or WIDE_BUILD_DEVICE (on the GPU, from the primitives)."""
+        _check(lib.rt_scene_set_wide_build(self.h, where))
 
     @property
     def num_prims(self):

@@ -149,6 +149,7 @@ struct rt_scene {
     DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats, d_xforms;
     DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
     WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
+    int wide_build = RT_WIDE_BUILD_COLLAPSE;            // where the wide tree is made: rt_scene_set_wide_build
     DevScene dev{};
     std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
 };
@@ -454,6 +455,23 @@ static int apply_traversal(rt_scene* s, int mode) {
         s->dev.units_oct = s->d_units_oct.p;
     }
     if (mode == RT_TRAVERSAL_WIDE && s->ctx) {
+        if (!s->d_wide_nodes.p && s->wide_build == RT_WIDE_BUILD_DEVICE) {     // first use: built on this GPU
+            int rc = set_device(s->ctx);
+            if (rc) return rc;
+            WideDeviceTree t;
+            std::string err;
+            const auto t_begin = std::chrono::steady_clock::now();
+            if (build_wide_on_device((void*)s->ctx->stream, s->d_entries.p, s->dev.n_entries, t, err))
+                return fail(RT_ERR_DEVICE, "wide traversal, device build: " + err);
+            if (std::getenv("RT_BUILD_TIMING"))
+                std::fprintf(stderr, "[rt build] wide tree on the GPU         %.3f s (%u node slots, %u primitives, %u levels)\n",
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), t.n_slots,
+                             t.n_prims, t.depth);
+            s->d_wide_nodes.release(); s->d_wide_nodes.p = t.nodes; s->d_wide_nodes.bytes = t.nodes_bytes;
+            s->d_wide_prims.release(); s->d_wide_prims.p = t.prims; s->d_wide_prims.bytes = t.prims_bytes;
+            s->wide.depth = t.depth;
+            s->wide.node_words = t.node_words;
+        }
         if (!s->d_wide_nodes.p) {  // first use: the wide tree, collapsed from the device's entry array
             int rc = set_device(s->ctx);
             if (rc) return rc;
@@ -562,6 +580,18 @@ int rt_scene_set_cache_dir(rt_scene* s, const char* dir) {
 }
 
 int rt_scene_cache_state(const rt_scene* s) { return s ? s->cache_state : RT_CACHE_OFF; }
+
+int rt_scene_set_wide_build(rt_scene* s, int where) {
+    if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_wide_build: NULL scene");
+    if (where != RT_WIDE_BUILD_COLLAPSE && where != RT_WIDE_BUILD_DEVICE) return fail(RT_ERR_INVALID, "unknown wide build");
+    if (s->d_wide_nodes.p) return fail(RT_ERR_STATE, "rt_scene_set_wide_build: the scene's wide tree has been made already");
+    s->wide_build = where;
+    for (rt_scene* r : s->replicas) {
+        int rc = rt_scene_set_wide_build(r, where);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
 
 int rt_scene_set_traversal(rt_scene* s, int mode) {
     RT_GUARD_BEGIN
@@ -680,6 +710,7 @@ int rt_scene_commit(rt_scene* s) {
         r->root_kind = s->root_kind;
         r->build_mode = s->build_mode;
         r->traversal = s->traversal;
+        r->wide_build = s->wide_build;
         rc = upload_scene(r, s->flat);
         if (rc) {                              // leave no half-made copies behind: a later commit starts afresh
             const std::string why = g_last_error;

@@ -167,6 +167,17 @@ struct WideScene {
 // empty string on success
 std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out);
 
+// The same tree built on the GPU from the device's entry array (rt_wide_device.hip): Morton-sorted
+// primitives, children = runs of equal Morton digit.  The arrays are device memory the caller owns
+// (hipFree) on success.  Runs on `stream` (a hipStream_t) of the current device and waits for it.
+struct WideDeviceTree {
+    void* nodes = nullptr;
+    void* prims = nullptr;
+    size_t nodes_bytes = 0, prims_bytes = 0;
+    uint32_t n_slots = 0, n_prims = 0, depth = 0, node_words = WIDE_NODE_WORDS;
+};
+int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries, WideDeviceTree& out, std::string& error);
+
 // ---------------------------------------------------------------------------------------------
 // Device side
 // ---------------------------------------------------------------------------------------------

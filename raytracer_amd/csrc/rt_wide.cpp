@@ -37,7 +37,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <exception>
 #include <memory>
+#include <string>
 #include <thread>
 
 #include "rt_internal.hpp"
@@ -278,6 +280,10 @@ struct WideBuilder {
         // arena, appended afterwards in slot order (the layout does not depend on timing)
         std::unique_ptr<Arena> sub[8];
         std::thread workers[8];
+        struct JoinAll {                           // whatever happens below, no thread is left running
+            std::thread* t;
+            ~JoinAll() { for (int s = 0; s < 8; s++) if (t[s].joinable()) t[s].join(); }
+        } join_all{workers};
         for (int s = 0; s < 8; s++) {
             if (!(imask >> s & 1)) continue;
             const Item& it = items[(size_t)child_in[s]];
@@ -289,7 +295,13 @@ struct WideBuilder {
                 std::vector<Item> ck;
                 children(it, ck);
                 workers[s] = std::thread([this, ck, B, out, depth, fork_levels]() {
-                    *out = make_node(ck, *B, 0, depth + 1, fork_levels - 1);
+                    try {                              // (nothing may leave a thread: an exception there ends the process)
+                        *out = make_node(ck, *B, 0, depth + 1, fork_levels - 1);
+                    } catch (const std::exception& e) {
+                        B->error = std::string("wide tree: ") + e.what();
+                    } catch (...) {
+                        B->error = "wide tree: unknown failure";
+                    }
                 });
             }
         }

@@ -20,6 +20,8 @@ pub const RT_TRAVERSAL_SWEEP: c_int = 2;
 pub const RT_TRAVERSAL_ORDERED: c_int = 3;
 pub const RT_TRAVERSAL_OCTANT: c_int = 4;
 pub const RT_TRAVERSAL_WIDE: c_int = 5;
+pub const RT_WIDE_BUILD_COLLAPSE: c_int = 0;
+pub const RT_WIDE_BUILD_DEVICE: c_int = 1;
 pub const RT_BUILD_REFERENCE: c_int = 0;
 pub const RT_BUILD_SAH: c_int = 1;
 pub const RT_CACHE_OFF: c_int = 0;
@@ -96,6 +98,7 @@ extern "C" {
     pub fn rt_scene_end_group(scene: *mut rt_scene) -> c_int;
     pub fn rt_scene_set_root(scene: *mut rt_scene, root_kind: c_int) -> c_int;
     pub fn rt_scene_set_traversal(scene: *mut rt_scene, mode: c_int) -> c_int;
+    pub fn rt_scene_set_wide_build(scene: *mut rt_scene, where_: c_int) -> c_int;
     pub fn rt_scene_set_build(scene: *mut rt_scene, mode: c_int) -> c_int;
     pub fn rt_set_default_build(mode: c_int) -> c_int;
     pub fn rt_set_default_cache_dir(dir: *const c_char) -> c_int;

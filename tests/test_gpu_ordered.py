@@ -202,3 +202,36 @@ def test_wide_walk_adversarial_rays_and_frames(rt, ob, ctx, monkeypatch):
         differing = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).mean()
         print(f"{name}: pixels that differ between the wide walk and the reference order: {differing:.2e}")
         assert differing <= 1e-3
+
+
+def test_wide_tree_built_on_the_gpu(rt, ob, ctx):
+    """RT_WIDE_BUILD_DEVICE: the eight-child nodes made on the GPU from the primitives alone (Morton
+    sort, runs of equal digit) instead of collapsed from the host's binary trees.  Same walk, same
+    bar: hit / miss and t as the oracle's on every ray, the primitive unless two tie."""
+    from helpers import adversarial_rays, random_mesh
+    cases = []
+    for name in ("cornell_box_plane.obj", "cornell_box.obj"):
+        osc = ob.Scene.cornell_box(asset(name))
+        cases.append((osc, osc.record_rays(96, 96, 4, 8, cap=150000, stride=1), True))
+    for osc in (ob.Scene.world1(), ob.Scene.world2(asset("thing.obj"), 1)):
+        cases.append((osc, osc.record_rays(128, 96, 4, 6, cap=150000), True))
+    mats, objects, _ = random_scene(ob, 3, n_spheres=51, n_meshes=3, tris_per_mesh=150)
+    rays = np.concatenate([random_rays(ob, 13, 120000, -12.0, 12.0), adversarial_rays(rt, 8, 60000, 10.0)])
+    rays = rays[(np.abs(rays["d"]).max(axis=1) < 1e9) & (np.abs(rays["d"]).max(axis=1) > 1e-15)]   # (see the wide walk's rule for other rays)
+    cases.append((ob.Scene.from_description(mats, objects, ob.ROOT_BVH), rays, True))
+    rng = np.random.default_rng(0)
+    one = np.zeros(1, dtype=ob.sphere_dt)
+    one["r"] = 1.0
+    same = np.repeat(random_mesh(ob, rng, 1, extent=2.0), 20)          # twenty copies of one triangle: equal keys throughout
+    few = random_rays(ob, 1, 5000, -3.0, 3.0)
+    for objs, root, same_prim in (([("spheres", one)], ob.ROOT_SINGLE, True), ([], ob.ROOT_BVH, True),
+                                  ([("mesh", random_mesh(ob, rng, 3, extent=2.0))], ob.ROOT_SINGLE, True),
+                                  ([("mesh", same)], ob.ROOT_SINGLE, False)):
+        cases.append((ob.Scene.from_description(mats, objs, root), few, same_prim))
+    for osc, rays, same_prim in cases:
+        sc = mirror(rt, ctx, osc)
+        sc.set_wide_build(rt.WIDE_BUILD_DEVICE)
+        want, _ = osc.trace(rays)
+        _ordered_vs_oracle(rt, sc, rt.TRAVERSAL_WIDE, rays, want, same_prim=same_prim)
+        with pytest.raises(rt.RtError):            # the tree exists: where it is made can no longer change
+            sc.set_wide_build(rt.WIDE_BUILD_COLLAPSE)

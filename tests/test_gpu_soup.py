@@ -80,6 +80,15 @@ def test_soup_near_first_walks(rt, ob, ctx, soup, walk):
         world.scene.set_traversal(rt.TRAVERSAL_AUTO)
 
 
+def test_soup_wide_tree_built_on_the_gpu(rt, ob, ctx, soup):
+    _, osc, rays, want = soup
+    world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
+    world.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
+    world.scene.set_traversal(rt.TRAVERSAL_WIDE)
+    _same_up_to_ties(rt, world.scene.trace(rays), want, "wide tree built on the GPU")
+    world.close()
+
+
 def test_soup_sah_tree(rt, ob, ctx, soup):
     _, osc, rays, want = soup
     rt.set_default_build(rt.BUILD_SAH)
