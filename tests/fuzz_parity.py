@@ -80,26 +80,39 @@ def main():
         osc = ob.Scene.from_description(mats, objects, root)
         sc = rt.Scene(ctx, mats, objects, root)
         sah = rt.Scene(ctx, mats, objects, root, build=rt.BUILD_SAH)
+        dev = rt.Scene(ctx, mats, objects, root)               # its wide tree is built on the GPU from the primitives alone
+        dev.set_wide_build(rt.WIDE_BUILD_DEVICE)
         tie_log = []
         host_entries = None
+        forms_run = set()
         batches = [("random", random_rays(ob, seed + 100, 200000, -12.0, 12.0)), ("adversarial", adversarial_rays(rt, seed, 100000, 12.0))]
         for name, rays in batches:
             want, _ = osc.trace(rays)
             for scene, mode, label in ((sc, rt.TRAVERSAL_PER_LANE, "per-lane"), (sc, rt.TRAVERSAL_SWEEP, "sweep"),
                                        (sc, rt.TRAVERSAL_ORDERED, "ordered"), (sc, rt.TRAVERSAL_OCTANT, "octant"),
                                        (sah, rt.TRAVERSAL_PER_LANE, "SAH per-lane"), (sah, rt.TRAVERSAL_OCTANT, "SAH octant"),
-                                       (sc, rt.TRAVERSAL_WIDE, "wide"), (sah, rt.TRAVERSAL_WIDE, "SAH wide")):
+                                       (sc, rt.TRAVERSAL_WIDE, "wide"), (sah, rt.TRAVERSAL_WIDE, "SAH wide"),
+                                       (dev, rt.TRAVERSAL_WIDE, "wide, built on the GPU")):
                 try:
                     scene.set_traversal(mode)
                 except rt.RtError:                  # trees nested too deep for the near-first walks; the forms
                     continue                        # that refuse transformed meshes or boxes of several children
+                forms_run.add(label)
                 n = len(rays) if scene.num_entries <= 600 or mode != rt.TRAVERSAL_SWEEP else 30000
                 got = scene.trace(rays[:n])
                 w = want[:n]
+                shown = rays[:n]
+                if scene is dev:
+                    # the device-built tree does not mark the objects of a list at the root, which the reference
+                    # tests without a box: the rays whose sphere test leaves f32's range (the collapsed tree's
+                    # rule for them is in rt_wide.cpp) are outside what it promises
+                    big = np.abs(rays[:n]["d"]).max(axis=1)
+                    sane = (big < 1e9) & (big > 1e-15)
+                    got, w, shown = got[sane], w[sane], shown[sane]
                 hit = (w["prim_id"] != rt.MISS) & ~(np.isnan(w["t"]) & np.isnan(got["t"]))   # NaN payloads differ by hardware
                 m_prim = int((got["prim_id"] != w["prim_id"]).sum())
                 m_t = int((got["t"][hit].view(np.uint32) != w["t"][hit].view(np.uint32)).sum())
-                if mode in (rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT, rt.TRAVERSAL_WIDE) or scene is sah:
+                if mode in (rt.TRAVERSAL_ORDERED, rt.TRAVERSAL_OCTANT, rt.TRAVERSAL_WIDE) or scene is sah or scene is dev:
                     # a hit distance that overflowed (inf, or the NaN of an overflowed sphere discriminant, which
                     # the reference accepts and hands on as t_max) ties with every other such hit: which one
                     # a walk reports depends on its visiting order, like the primitive of any tie
@@ -111,7 +124,7 @@ def main():
                     if m_prim:
                         tie_log.append(f"{label} {name}: {m_prim}")
                     m_prim = int(((got["prim_id"] == rt.MISS) != (w["prim_id"] == rt.MISS)).sum())
-                if mode == rt.TRAVERSAL_WIDE and (m_prim or m_t):
+                if mode == rt.TRAVERSAL_WIDE and scene is not dev and (m_prim or m_t):
                     # The wide walk's boxes enclose the reference's, so it can keep a hit that the reference's walk
                     # loses where rounding closes a box in front of a primitive whose own test accepts the ray
                     # (directions of magnitude 1e-20: |d|^2 is a denormal).  Such a hit is nearer than the
@@ -136,10 +149,10 @@ def main():
                     bad += 1
                     k = np.nonzero((got["prim_id"] != w["prim_id"]) if m_prim else
                                    (hit & (got["t"].view(np.uint32) != w["t"].view(np.uint32))))[0][:3]
-                    print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {rays[k]}: "
+                    print(f"seed {seed} {name} {label}: {m_prim} primitive and {m_t} t mismatches; e.g. rays {shown[k]}: "
                           f"t {got['t'][k]} / {w['t'][k]}, primitive {got['prim_id'][k]} / {w['prim_id'][k]}")
         print(f"seed {seed}: {sc.num_entries} entries{' (nested)' if seed % 3 == 0 else ''}, root {root}, "
-              f"hits {(want['prim_id'] != rt.MISS).mean():.2f} ok" + (f"  ties: {'; '.join(tie_log)}" if tie_log else ""), flush=True)
+              f"hits {(want['prim_id'] != rt.MISS).mean():.2f}, {len(forms_run)} forms ok" + (f"  ties: {'; '.join(tie_log)}" if tie_log else ""), flush=True)
     print("mismatching batches:", bad, " primitives that differ under the near-first walks (ties in t):", ties,
           " hits of the wide walk that the reference's own primitive test confirms and its walk loses:", regained)
     return 1 if bad else 0
