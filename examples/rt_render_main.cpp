@@ -8,7 +8,7 @@
 //
 //   rt_render [--scene cornell|cornell_plane|world1|world2|world2_glass] [--obj FILE] [--size WxH]
 //             [--spp N] [--depth N] [--seed N] [--device N | --gpus N | --devices a,b,..] [--sah]
-//             [--progressive] [--out FILE.ppm]
+//             [--wide | --wide-device] [--progressive] [--out FILE.ppm]
 //
 // --gpus N renders on GPUs 0 .. N-1 of the node through one multi-GPU context (the reference's one
 // render() owns all its workers, main.rs:319-336, 443): the scene is built once and uploaded to every
@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
     int device = 0;
     std::vector<int> devices;
     bool progressive = false, sah = false;
+    int wide = 0;                              // 1: RT_TRAVERSAL_WIDE on the tree collapsed on the host, 2: on the tree built on the GPU
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char* {
@@ -80,6 +81,8 @@ int main(int argc, char** argv) {
         }
         else if (a == "--progressive") progressive = true;
         else if (a == "--sah") sah = true;
+        else if (a == "--wide") wide = 1;
+        else if (a == "--wide-device") wide = 2;
         else { std::fprintf(stderr, "rt_render: unknown argument %s\n", a.c_str()); return 2; }
     }
 
@@ -99,6 +102,10 @@ int main(int argc, char** argv) {
         rc = rt_world_create_cornell_box(ctx, obj.c_str(), &world);
     } else { std::fprintf(stderr, "rt_render: unknown scene %s\n", scene.c_str()); return 2; }
     if (rc) return die("scene");
+    if (wide) {                                // the opt-in eight-child tree: collapsed on the host, or built on the GPU
+        if (wide == 2 && rt_scene_set_wide_build(rt_world_scene(world), RT_WIDE_BUILD_DEVICE)) return die("rt_scene_set_wide_build");
+        if (rt_scene_set_traversal(rt_world_scene(world), RT_TRAVERSAL_WIDE)) return die("rt_scene_set_traversal");
+    }
     const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - now).count();
 
     Window win;
