@@ -420,6 +420,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
                        "build": args.build, "traversal": args.traversal, "kernel_form": form_name,
+                       **({"wide_build": args.wide_build} if args.traversal == "wide" else {}),
                        "parallelism": (f"{world} processes x 1 GPU, torch.distributed reduce" if per_process else
                                        f"1 process x {world} GPU(s), rt_render_multi (RCCL reduce in the library)"),
                        "partition": "rt_partition: interleaved 64-row bands x sample ranges",

@@ -68,9 +68,14 @@ def test_wide_walk_on_every_gpu_of_a_context():
     assert one["config"]["kernel_form"] == "wide_refill"
     plain = _run(1)
     assert one["config"]["rays_per_step"] == pytest.approx(plain["config"]["rays_per_step"], rel=1e-4)     # (ties aside)
-    for extra in (["--share-gpus", "--traversal", "wide"], ["--traversal", "wide"]):
+    # (the last one: every worker builds the tree itself on its GPU, from the primitives alone)
+    for extra in (["--share-gpus", "--traversal", "wide"], ["--traversal", "wide"],
+                  ["--share-gpus", "--traversal", "wide", "--wide-build", "device"]):
         many = _run(3, extra=extra)
         assert many["n_gpus"] == 3 and many["config"]["kernel_form"] == "wide_refill"
+        if "device" in extra:                  # another tree: the same rays up to ties
+            assert many["config"]["rays_per_step"] == pytest.approx(one["config"]["rays_per_step"], rel=1e-4)
+            continue
         assert many["config"]["rays_per_step"] == one["config"]["rays_per_step"]
         assert many["config"]["accum_sum"] == pytest.approx(one["config"]["accum_sum"], rel=1e-5)
 
