@@ -67,12 +67,13 @@ SHADE_BYTES_PER_RAY = 4.0 + 48.0 + 8.0 + 20.0 + 48.0
 RAYGEN_BYTES_PER_PATH = 48.0
 
 
-def trace_bytes_per_ray(n_box, n_tri, n_sph):
+def trace_bytes_per_ray(n_box, n_tri, n_sph, box_bytes=32.0):
     """Algorithmic bytes the closest-hit kernel moves per ray: 32 B per box test (24 B box + 8 B
     links), 36 B per triangle test (three positions), 16 B per sphere test (centre + radius),
     plus the ray record read (origin, direction, path slot, rng key: 32 B), the hit record written
-    (8 B) and the queue index written (4 B)."""
-    return 32.0 * n_box + 36.0 * n_tri + 16.0 * n_sph + 32.0 + 8.0 + 4.0
+    (8 B) and the queue index written (4 B).  The opt-in wide walk counts node visits where the
+    others count box tests: a node of eight 8-bit boxes is 80 B."""
+    return box_bytes * n_box + 36.0 * n_tri + 16.0 * n_sph + 32.0 + 8.0 + 4.0
 
 
 def kernel_source_hash():
@@ -390,7 +391,7 @@ def main():
     if rank == 0:
         mean = accum.view(height, width, 3).mean().item() / spp
         value = total_rays / elapsed_max / 1e6
-        bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph)
+        bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph, 80.0 if args.traversal == "wide" else 32.0)
         # the dominant kernel on one GPU (rank 0's, or the slowest GPU's of a one-process job):
         # algorithmic bytes of its launches / their summed duration.  Staged: the closest-hit kernel
         # alone.  Default: the per-batch kernel, which also holds raygen and shade, so their stream
