@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
@@ -39,7 +40,37 @@ __global__ void __launch_bounds__(256) k_stream16(const u4* __restrict__ table, 
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-int main() {
+// With table sizes (MiB) as arguments: the random-line rate per size, second of two runs -- what a
+// table that fits the 256 MiB last-level cache (or the L2s) delivers against one that does not.
+static int sweep(int argc, char** argv) {
+    const int blocks = 256 * 8 * 4;
+    uint32_t* out;
+    CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int a = 1; a < argc; a++) {
+        const size_t bytes = (size_t)atol(argv[a]) << 20, n_slots = bytes / 16;
+        u4* table;
+        CHECK(hipMalloc(&table, bytes));
+        CHECK(hipMemset(table, 1, bytes));
+        float ms = 0;
+        for (int rep = 0; rep < 2; rep++) {
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_random16, blocks, 256, 0, 0, table, n_slots, out);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        const double loads = (double)blocks * 256 * LOADS;
+        printf("table %6ld MiB: %.3f ms, %.0f M random 16-byte lane loads/s = %.2f TB/s of 128-byte lines\n", atol(argv[a]), ms,
+               loads / ms / 1e3, loads * 128 / ms / 1e9);
+        CHECK(hipFree(table));
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1) return sweep(argc, argv);
     const size_t bytes = 8ull << 30;               // 8 GiB: 32 x the 256 MiB last-level cache
     const size_t n_slots = bytes / 16;
     u4* table; uint32_t* out;
