@@ -234,3 +234,30 @@ def test_wide_tree_refuses_transformed_meshes(rt, ob):
     sc = rt.Scene(None, mats, [("mesh", random_mesh(ob, rng, 5), m.reshape(-1))], ob.ROOT_SINGLE)
     with pytest.raises(rt.RtError):
         sc.wide()
+
+
+def test_threaded_wide_build_is_deterministic(rt, ob):
+    """Big subtrees near the root are collapsed on threads of their own, each into its own arena, and
+    appended in slot order: the arrays do not depend on timing.  200 k triangles (400 k entries: the
+    root's children are past the size that gets a thread), twice, bit for bit; and every node slot
+    the walk can reach holds a node (first-fit compaction left no dangling base)."""
+    arrays = []
+    for _ in range(2):
+        w = rt.World.soup(None, 200000, grid=8, seed=7)
+        nodes, prims, depth = w.scene.wide()
+        arrays.append((nodes.copy(), prims.copy(), depth))
+        w.close()
+    assert arrays[0][2] == arrays[1][2] and 6 <= arrays[0][2] <= 16
+    assert np.array_equal(arrays[0][0], arrays[1][0]) and np.array_equal(arrays[0][1].view(np.uint32), arrays[1][1].view(np.uint32))
+    nodes, prims, _ = arrays[0]
+    assert len(prims) == 200000 + 64 + 1
+    imask, lmask = nodes[:, 3] >> 24, nodes[:, 6]
+    reach = np.zeros(len(nodes), dtype=bool)
+    reach[0] = True
+    for s in range(8):                               # children named by some node
+        has = (imask >> s & 1).astype(bool)
+        reach[nodes[has, 4] + s] = True
+    used = (imask | lmask) != 0
+    assert np.array_equal(reach, used)               # named <=> holds a node
+    assert used.mean() > 0.85                        # mostly nodes, few holes
+    assert int(np.array([bin(int(m)).count("1") for m in lmask[used]]).sum()) == len(prims)
