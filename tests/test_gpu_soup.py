@@ -15,7 +15,9 @@ description goes to the oracle.  RT_TEST_SOUP_TRIS overrides the size.
 * the full workload (10 M triangles, 3840 x 2160, 256 spp, depth 16): the frame twice is the same
   frame bit for bit, its paths are counted exactly, and mean radiance and rays per path agree with
   the oracle's render of the same scene at 480 x 270 and 4 spp (the largest oracle render that
-  keeps this test to a couple of minutes; both are unbiased estimates of the same integrals)."""
+  keeps this test to a couple of minutes; both are unbiased estimates of the same integrals); the
+  same frame through the opt-in wide walk (tree collapsed on the host, and built on the GPU): the
+  same rays and pixels up to ties, in less than half the time."""
 import os
 
 import numpy as np
@@ -162,4 +164,21 @@ def test_soup_full_size_frame(rt, ob, ctx):
           f"oracle {mean_cpu:.5f}; rays per path gpu {st['rays_traced'] / st['paths']:.4f} oracle {ost['rays'] / ost['paths']:.4f}")
     assert abs(mean_gpu - mean_cpu) <= 0.03 * mean_cpu
     assert abs(st["rays_traced"] / st["paths"] - ost["rays"] / ost["paths"]) < 0.03
+    # the same frame through the opt-in wide walk, its tree collapsed on the host, then built on the GPU:
+    # the same RNG keys, so a path changes only where a tie in t goes to another primitive
+    world.scene.set_traversal(rt.TRAVERSAL_WIDE)
+    wide, st_w = render()
+    world.close()
+    world = rt.World.soup(ctx, n, grid=64, seed=12345)
+    world.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
+    world.scene.set_traversal(rt.TRAVERSAL_WIDE)
+    dev, st_d = render()
+    for label, img, s2 in (("collapsed", wide, st_w), ("built on the GPU", dev, st_d)):
+        differing = float((img.view(torch.int32) != frame.view(torch.int32)).view(-1, 3).any(dim=1).float().mean())
+        print(f"soup_10m_4k_256, wide walk, tree {label}: {s2['rays_traced']} rays in {s2['ms_render']:.0f} ms "
+              f"({st['ms_render'] / s2['ms_render']:.1f} x the reference-order walk); pixels that differ {differing:.2e}")
+        assert rt.FORM_NAMES[s2["kernel_form"]] == "wide_refill" and s2["paths"] == st["paths"]
+        assert abs(s2["rays_traced"] - st["rays_traced"]) <= 1e-5 * st["rays_traced"]
+        assert differing <= 1e-4
+        assert s2["ms_render"] < 0.5 * st["ms_render"]
     world.close()
