@@ -261,3 +261,23 @@ def test_threaded_wide_build_is_deterministic(rt, ob):
     assert np.array_equal(reach, used)               # named <=> holds a node
     assert used.mean() > 0.85                        # mostly nodes, few holes
     assert int(np.array([bin(int(m)).count("1") for m in lmask[used]]).sum()) == len(prims)
+
+
+@pytest.mark.parametrize("root", [0, 2])
+def test_wide_tree_of_nested_containers(rt, ob, root):
+    """Containers inside containers (a Bvh of spheres, a HittableList holding a mesh and another Bvh,
+    an empty Bvh): the collapse follows the flattened entries, so nesting costs nothing; under a list
+    root only the root's own objects are marked as reached without a box."""
+    from helpers import adversarial_rays
+    from test_host_layer import _nested_description
+    mats, objects = _nested_description(ob, 17, with_xforms=False)
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root)
+    nodes, prims, depth = sc.wide()
+    _check_structure(nodes, prims, depth, sc.entries())
+    marked = sum(bin(int(n[7])).count("1") for n in nodes)
+    assert (marked > 0) == (root == 2)
+    rays = np.concatenate([random_rays(ob, 3, 250, -5.0, 5.0), adversarial_rays(rt, 4, 150, 5.0)])
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    assert (want["prim_id"] != 0xFFFFFFFF).sum() > 25
+    assert _compare(nodes, prims, rays, want) <= 1
