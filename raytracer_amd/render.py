@@ -63,6 +63,8 @@ def main(argv=None):
     ap.add_argument("--depth", type=int, default=6)        # main.rs:21
     ap.add_argument("--seed", type=lambda v: int(v, 0), default=rt.DEFAULT_SEED)
     ap.add_argument("--sah", action="store_true", help="opt-in SAH mesh trees")
+    ap.add_argument("--wide", choices=["off", "collapse", "device"], default="off",
+                    help="the opt-in wide walk: eight-child tree collapsed on the host from the binary trees, or built on the GPU")
     ap.add_argument("--backend", default=os.environ.get("RT_DIST_BACKEND", ""))
     ap.add_argument("--out", default="frame.ppm")
     args = ap.parse_args(argv)
@@ -78,6 +80,10 @@ def main(argv=None):
     if args.sah:
         rt.set_default_build(rt.BUILD_SAH)
     world = make_world(ctx, args.scene, args.obj)
+    if args.wide != "off":
+        if args.wide == "device":
+            world.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
+        world.scene.set_traversal(rt.TRAVERSAL_WIDE)
     accum, st = render_frame(world, width, height, args.spp, args.depth, rank, world_size, device, args.seed)
     if rank == 0:
         packed = torch.zeros(height * width, dtype=torch.int32, device=device)

@@ -186,3 +186,11 @@ def test_render_module_two_ranks_write_the_one_rank_frame(tmp_path):
         frames.append(np.frombuffer(raw[len(header):], dtype=np.uint8).astype(int))
     assert len(frames[0]) == 96 * 80 * 3 and frames[0].max() > 100
     assert np.abs(frames[0] - frames[1]).max() <= 1
+    # one rank through the opt-in wide walk, its tree built on the GPU: the same picture unless a tie in t
+    # goes to another primitive
+    out = tmp_path / "wide.ppm"
+    p = subprocess.run([sys.executable, "-m", "raytracer_amd.render"] + args + ["--wide", "device", "--out", str(out)],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    wide = np.frombuffer(out.read_bytes()[len(header):], dtype=np.uint8).astype(int)
+    assert (wide.reshape(-1, 3) != frames[0].reshape(-1, 3)).any(axis=1).mean() <= 2e-3
