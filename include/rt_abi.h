@@ -244,8 +244,24 @@ int rt_scene_set_wide_build(rt_scene* scene, int where);
 int rt_scene_commit(rt_scene* scene);
 size_t rt_scene_num_prims(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
-/* host-only scenes: copies the flattened pre-order entry array (16 floats per entry) */
+/* host-only scenes: copies the flattened pre-order entry array (16 floats per entry).  Word 3 of an
+ * entry holds its kind in bits 30-31 (0 box, 1 triangle, 2 sphere) and, for a box, the index of the
+ * entry behind its subtree; word 7 of a triangle or sphere entry holds the primitive's KEY. */
 int rt_scene_get_entries(const rt_scene* scene, float* out, size_t n_floats);
+/* Primitive keys (no counterpart in the reference, which has no primitive ids at all).  Inside the
+ * library a primitive is named by a key made from its RANK: its place in the order in which the
+ * reference's recursion visits the primitives (Bvh::hit / Mesh::bvh_hit left child first,
+ * shape.rs:142-158, 292-324; HittableList in order, shape.rs:60-74), i.e. the pre-order of the
+ * reference-topology trees -- whatever tree and visiting order the scene is traced with:
+ *     triangle: key = 0x3FFFFFFE - rank          sphere: key = 0x40000000 | rank
+ * The keys carry the reference's resolution of exact ties in t into walks that visit in another
+ * order.  The reference lets a triangle replace the closest hit only when t < t_max (shape.rs:297)
+ * and a sphere when root <= t_max (shape.rs:32-36); so of the primitives that tie at the smallest
+ * t it reports the sphere it visits last, or without a sphere the triangle it visits first: the
+ * primitive of the largest key.  Every walk that is not in the reference's order accepts a
+ * primitive when t < t_max, or when t == t_max and its key is the larger one.
+ * rt_scene_get_prim_order() copies the table rank -> primitive id (n = rt_scene_num_prims()). */
+int rt_scene_get_prim_order(const rt_scene* scene, uint32_t* out, size_t n);
 /* host-only scenes: the same entries as the per-lane walks read them, in 16-byte units (4 floats):
  * a box or a sphere is the first 8 floats of its entry in two units, a triangle the first 11 in
  * three, followed by the distance to the next entry (3, or 4 where a padding unit keeps a box or

@@ -112,6 +112,7 @@ def _load():
         "rt_scene_num_prims": (sz, [vp]),
         "rt_scene_num_entries": (sz, [vp]),
         "rt_scene_get_entries": (i32, [vp, vp, sz]),
+        "rt_scene_get_prim_order": (i32, [vp, vp, sz]),
         "rt_scene_num_units": (sz, [vp]),
         "rt_scene_get_units": (i32, [vp, vp, sz]),
         "rt_scene_num_walk_units": (sz, [vp]),
@@ -166,7 +167,7 @@ ABI_SYMBOLS = [
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
     "rt_scene_set_traversal", "rt_scene_set_wide_build", "rt_set_default_cache_dir", "rt_scene_set_cache_dir", "rt_scene_cache_state", "rt_scene_commit",
-    "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_num_units",
+    "rt_scene_num_prims", "rt_scene_num_entries", "rt_scene_get_entries", "rt_scene_get_prim_order", "rt_scene_num_units",
     "rt_scene_get_units", "rt_scene_num_walk_units", "rt_scene_get_walk_units", "rt_scene_wide_info", "rt_scene_get_wide", "rt_trace",
     "rt_trace_device", "rt_trace_device_static", "rt_render", "rt_render_device", "rt_tonemap", "rt_tonemap_device",
 ]
@@ -340,31 +341,105 @@ class Scene:
     def num_entries(self):
         return lib.rt_scene_num_entries(self.h)
 
-    def entries(self):
+    # The flattened arrays name a primitive by its key (rt_abi.h, "Primitive keys").  The accessors
+    # below return the arrays as the device holds them with raw=True; by default the key words are
+    # replaced by primitive ids, which is what a reader of the arrays wants to compare hits by.
+    def _keys_to_ids(self, words, where):
+        if len(where):
+            words[where] = self.prim_of_key(words[where])
+
+    def entries(self, raw=False):
         n = self.num_entries
         out = np.zeros((n, 16), dtype=np.float32)
         _check(lib.rt_scene_get_entries(self.h, _ptr(out), out.size))
+        if not raw:
+            u = out.view(np.uint32)
+            tags = u[:, 3] >> 30
+            rows = np.nonzero((tags == 1) | (tags == 2))[0]
+            col = u[:, 7].copy()
+            self._keys_to_ids(col, rows)
+            u[:, 7] = col
         return out
 
-    def units(self):
+    def prim_order(self):
+        """rank -> primitive id: the order in which the reference's recursion visits the primitives."""
+        out = np.zeros(self.num_prims, dtype=np.uint32)
+        _check(lib.rt_scene_get_prim_order(self.h, _ptr(out), len(out)))
+        return out
+
+    def prim_of_key(self, key):
+        """Primitive id(s) of the key(s) the flattened arrays name primitives by (MISS stays MISS)."""
+        k = np.asarray(key, dtype=np.uint32)
+        low = (k & np.uint32(0x3FFFFFFF)).astype(np.int64)
+        rank = np.where((k & np.uint32(0x40000000)) != 0, low, 0x3FFFFFFE - low)
+        order = self.prim_order()
+        miss = k == np.uint32(MISS)
+        if len(order) == 0:
+            out = np.full(k.shape, MISS, dtype=np.uint32)
+        else:
+            out = np.where(miss, np.uint32(MISS), order[np.where(miss, 0, rank) % len(order)])
+        return out if out.ndim else int(out)
+
+    def units(self, raw=False):
         """The entries as the per-lane walks read them: (n_units, 4) floats, 16-byte units."""
         out = np.zeros((lib.rt_scene_num_units(self.h), 4), dtype=np.float32)
         _check(lib.rt_scene_get_units(self.h, _ptr(out), out.size))
+        if not raw and len(out):
+            u = out.view(np.uint32)
+            starts, i, n = [], 0, len(out)
+            while i < n:                           # entries follow each other; a triangle names its own length
+                tag = int(u[i, 3]) >> 30
+                if tag in (1, 2):
+                    starts.append(i)
+                i += int(u[i + 2, 3]) if tag == 1 else 2
+            rows = np.asarray(starts, dtype=np.int64) + 1
+            col = u[:, 3].copy()
+            self._keys_to_ids(col, rows)
+            u[:, 3] = col
         return out
 
-    def walk_units(self):
+    def walk_units(self, raw=False):
         """The units in the linked, locality-ordered form of the reference-order per-lane walks."""
         out = np.zeros((lib.rt_scene_num_walk_units(self.h), 4), dtype=np.float32)
         _check(lib.rt_scene_get_walk_units(self.h, _ptr(out), out.size))
+        if not raw and len(out):
+            u = out.view(np.uint32)
+            n = len(out)
+            seen, todo, starts = set([0]), [0], []
+            while todo:                            # every entry is reached through the links, from unit 0
+                i = todo.pop()
+                tag = int(u[i, 3]) >> 30
+                if tag == 0:
+                    nxt = [int(u[i, 3]) & 0x3FFFFFFF, int(u[i + 1, 3])]
+                elif tag == 1:
+                    starts.append(i)
+                    nxt = [int(u[i + 2, 3])]
+                else:
+                    if tag == 2:
+                        starts.append(i)
+                    nxt = [int(u[i + 1, 1])]
+                for j in nxt:
+                    if j < n and j not in seen:
+                        seen.add(j)
+                        todo.append(j)
+            rows = np.asarray(starts, dtype=np.int64) + 1
+            col = u[:, 3].copy()
+            self._keys_to_ids(col, rows)
+            u[:, 3] = col
         return out
 
-    def wide(self):
+    def wide(self, raw=False):
         """The wide tree of a host-only scene: (nodes (n, 20) uint32, primitive records (m, 16) float32, depth)."""
         n_nodes, n_prims, depth, words = C.c_size_t(), C.c_size_t(), C.c_uint32(), C.c_uint32()
         _check(lib.rt_scene_wide_info(self.h, C.byref(n_nodes), C.byref(n_prims), C.byref(depth), C.byref(words)))
         nodes = np.zeros((n_nodes.value, words.value), dtype=np.uint32)
         prims = np.zeros((n_prims.value, 16), dtype=np.float32)
         _check(lib.rt_scene_get_wide(self.h, _ptr(nodes), nodes.size, _ptr(prims) if prims.size else None, prims.size))
+        if not raw and len(prims):
+            u = prims.view(np.uint32)
+            col = u[:, 7].copy()
+            self._keys_to_ids(col, np.arange(len(prims)))
+            u[:, 7] = col
         return nodes, prims, depth.value
 
     def trace(self, rays, t_min=0.001, t_max=np.inf):

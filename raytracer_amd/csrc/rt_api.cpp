@@ -146,7 +146,7 @@ struct rt_scene {
     std::string cache_dir;              // rt_scene_set_cache_dir; empty: the scene is always built
     int cache_state = RT_CACHE_OFF;
     FlatScene flat;
-    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_mats, d_xforms;
+    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_order, d_mats, d_xforms;
     DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
     WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
     int wide_build = RT_WIDE_BUILD_COLLAPSE;            // where the wide tree is made: rt_scene_set_wide_build
@@ -520,6 +520,9 @@ static int apply_traversal(rt_scene* s, int mode) {
     s->dev.octant = mode == RT_TRAVERSAL_OCTANT ? 1u : 0u;
     s->dev.ordered = mode == RT_TRAVERSAL_ORDERED ? 1u : 0u;
     s->dev.wide = mode == RT_TRAVERSAL_WIDE && s->ctx ? 1u : 0u;
+    // out of the reference's visiting order (another tree, or nearer child first) exact ties in t are
+    // resolved by primitive key
+    s->dev.tie = (s->build_mode != RT_BUILD_REFERENCE || s->dev.octant || s->dev.ordered || s->dev.wide) ? 1u : 0u;
     s->auto_tuned = false;
     s->dev.refill = s->env_refill;
     s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
@@ -531,7 +534,8 @@ static int apply_traversal(rt_scene* s, int mode) {
         const uint32_t wait = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
         const uint64_t top_bytes = (uint64_t)s->dev.walk_top_units * 16u;
         if (wait > 0 && mode != RT_TRAVERSAL_ORDERED && mode != RT_TRAVERSAL_OCTANT && !s->dev.sweep && s->dev.n_xforms == 0 &&
-            top_bytes > 0 && top_bytes <= SPLIT_TOP_MAX_BYTES && s->dev.walk_top_units < s->dev.n_walk && !s->dev.lds_walk) {
+            top_bytes > 0 && top_bytes <= SPLIT_TOP_MAX_BYTES && s->dev.walk_top_units < s->dev.n_walk && !s->dev.lds_walk &&
+            !s->dev.tie) {
             s->dev.split_top = s->dev.walk_top_units;      // (whole sibling groups: no entry straddles the boundary)
             s->dev.deep_wait = wait;
             if (s->dev.refill == 0) s->dev.refill = 16;
@@ -642,6 +646,7 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     HIP_TRY(upload(s->d_walk, f.walk.data(), f.walk.size() * 4));
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
+    HIP_TRY(upload(s->d_order, f.prim_order.data(), f.prim_order.size() * 4));
     HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
     HIP_TRY(upload(s->d_xforms, f.xforms.data(), f.xforms.size() * 4));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -650,6 +655,7 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     s->dev.walk = s->d_walk.p;
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
+    s->dev.prim_order = (const uint32_t*)s->d_order.p;
     s->dev.materials = s->d_mats.p;
     s->dev.xforms = s->d_xforms.p;
     s->dev.n_xforms = (uint32_t)(f.xforms.size() / 32);
@@ -739,6 +745,14 @@ int rt_scene_get_entries(const rt_scene* s, float* out, size_t n_floats) {
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "rt_scene_get_entries needs a committed host-only scene");
     if (n_floats != s->flat.entries.size()) return fail(RT_ERR_INVALID, "rt_scene_get_entries: size mismatch");
     std::memcpy(out, s->flat.entries.data(), n_floats * sizeof(float));
+    return RT_OK;
+}
+
+int rt_scene_get_prim_order(const rt_scene* s, uint32_t* out, size_t n) {
+    if (!s || (!out && n)) return fail(RT_ERR_INVALID, "rt_scene_get_prim_order: NULL argument");
+    if (!s->committed) return fail(RT_ERR_STATE, "scene not committed");
+    if (n != s->flat.prim_order.size()) return fail(RT_ERR_INVALID, "rt_scene_get_prim_order: size mismatch");
+    if (n) std::memcpy(out, s->flat.prim_order.data(), n * sizeof(uint32_t));
     return RT_OK;
 }
 

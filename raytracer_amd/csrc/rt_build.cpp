@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <limits>
 #include <numeric>
 #include <thread>
@@ -228,9 +229,17 @@ struct Builder {
         const int next = (axis + 1) % 3;
         Box left_box, right_box;
         if (fork_levels > 0 && n >= 65536) {
-            std::thread left([&, this]() { left_box = fill_mesh_range(r, tmp, half, next, left_at, fork_levels - 1); });
+            // (an exception in either half -- bad_alloc from a sort's scratch -- must not reach a joinable
+            // thread's destructor: the left half reports through `thrown`, the guard joins on every path)
+            std::exception_ptr thrown;
+            std::thread left([&, this]() {
+                try { left_box = fill_mesh_range(r, tmp, half, next, left_at, fork_levels - 1); }
+                catch (...) { thrown = std::current_exception(); }
+            });
+            struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{left};
             right_box = fill_mesh_range(r + half, tmp + half, n - half, next, right_at, fork_levels - 1);
             left.join();
+            if (thrown) std::rethrow_exception(thrown);
         } else {
             left_box = fill_mesh_range(r, tmp, half, next, left_at, 0);
             right_box = fill_mesh_range(r + half, tmp + half, n - half, next, right_at, 0);
@@ -336,9 +345,15 @@ struct Builder {
         }
         const size_t left_at = at + 1, right_at = left_at + mesh_entries(half);
         if (fork_levels > 0 && n >= 65536) {
-            std::thread left([=]() { fill_mesh_range_sah(idx, half, left_at, fork_levels - 1, depth + 1); });
+            std::exception_ptr thrown;
+            std::thread left([=, &thrown]() {
+                try { fill_mesh_range_sah(idx, half, left_at, fork_levels - 1, depth + 1); }
+                catch (...) { thrown = std::current_exception(); }
+            });
+            struct Join { std::thread& t; ~Join() { if (t.joinable()) t.join(); } } join{left};
             fill_mesh_range_sah(idx + half, n - half, right_at, fork_levels - 1, depth + 1);
             left.join();
+            if (thrown) std::rethrow_exception(thrown);
         } else {
             fill_mesh_range_sah(idx, half, left_at, 0, depth + 1);
             fill_mesh_range_sah(idx + half, n - half, right_at, 0, depth + 1);
@@ -759,13 +774,96 @@ uint64_t hash_bytes(uint64_t h, const void* data, size_t n) {
     std::memcpy(&tail, p + i, n - i);
     return mix(h ^ tail ^ ((uint64_t)n << 56));
 }
-constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '3'};
+constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '4'};
+// Version of what the builder writes into the arrays (tree construction, entry and unit formats,
+// primitive keys, layout rules).  It is part of the cache key: bump it with any change to the
+// output of this file, and files of older builders are simply never found.
+constexpr uint32_t BUILDER_VERSION = 5;
 struct CacheHeader {
     char magic[8];
     uint64_t key;
-    uint64_t n_entries_f, n_units_f, n_walk_f, n_geo_f, n_meta, n_mat_f, n_xform_f;   // element counts of the arrays
+    uint64_t n_entries_f, n_units_f, n_walk_f, n_geo_f, n_meta, n_mat_f, n_xform_f, n_order;   // element counts of the arrays
     uint32_t kinds_present, has_spheres, depth, ordered_ok, walk_top_units, multi_child;
 };
+
+// Cheap structural checks of arrays read from a file: a damaged file whose header and tail
+// survived must not hand out-of-range links to the GPU walks.
+bool cache_arrays_sane(const FlatScene& f) {
+    auto wordv = [](const std::vector<float>& v, size_t i) { uint32_t u; std::memcpy(&u, &v[i], 4); return u; };
+    if (f.entries.size() % ENTRY_FLOATS || f.units.size() % 4 || f.walk.size() % 4 || f.prim_geo.size() % 4 ||
+        f.materials.size() % 8 || f.xforms.size() % 32)
+        return false;
+    const size_t n = f.n_entries(), n_prims = f.prim_meta.size(), n_mats = f.materials.size() / 8;
+    if (f.prim_geo.size() != n_prims * 4 || f.prim_order.size() != n_prims || n_prims > MAX_PRIMS || n_mats == 0) return false;
+    if (f.units.size() < UNITS_END * 4 || f.walk.size() < UNITS_END * 4) return false;
+    const size_t n_units = f.n_units(), n_walk = f.n_walk();
+    if (f.walk_top_units > n_walk || f.depth > n + 1) return false;
+    std::vector<uint8_t> seen(n_prims, 0);
+    for (uint32_t id : f.prim_order) {
+        if (id >= n_prims || seen[id]) return false;
+        seen[id] = 1;
+    }
+    for (uint32_t m : f.prim_meta)
+        if ((m & MAT_MASK) >= n_mats) return false;
+    size_t prims_seen = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t w = wordv(f.entries, i * ENTRY_FLOATS + 3), tag = w >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            const uint32_t skip = w & SKIP_MASK;
+            if (skip <= i || skip > n) return false;
+        } else if (tag == TAG_TRI || tag == TAG_SPH) {
+            const uint32_t key = wordv(f.entries, i * ENTRY_FLOATS + 7);
+            if (((key & KEY_SPHERE) != 0) != (tag == TAG_SPH) || (key & ~KEY_MASK)) return false;
+            const uint32_t rank = (key & KEY_SPHERE) ? (key & PRIM_ID_MASK) : (KEY_NONE - 1u - key);
+            if (rank >= n_prims) return false;
+            prims_seen++;
+        } else if (wordv(f.entries, i * ENTRY_FLOATS) == END_CODE_ENTER || wordv(f.entries, i * ENTRY_FLOATS) == END_CODE_LEAVE) {
+            if (wordv(f.entries, i * ENTRY_FLOATS + 1) >= f.xforms.size() / 32) return false;
+        } else {
+            return false;
+        }
+    }
+    if (prims_seen != n_prims) return false;
+    // pre-order units: entries follow each other, a triangle names its own length
+    for (size_t u = 0; u < n_units;) {
+        const uint32_t w = wordv(f.units, u * 4 + 3), tag = w >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            if ((w & SKIP_MASK) <= u || (w & SKIP_MASK) > n_units) return false;
+            u += 2;
+        } else if (tag == TAG_TRI) {
+            const uint32_t stride = wordv(f.units, u * 4 + 11);
+            if (stride != 3 && stride != 4) return false;
+            u += stride;
+        } else {
+            u += 2;
+        }
+        if (u > n_units) return false;
+    }
+    // linked units: every link reachable from unit 0 stays inside the array (n_walk = "done")
+    std::vector<uint8_t> visited(n_walk + 1, 0);
+    std::vector<uint32_t> todo;
+    if (n_walk) todo.push_back(0u);
+    auto push = [&](uint32_t u) -> bool {
+        if (u > n_walk) return false;
+        if (u < n_walk && !visited[u]) { visited[u] = 1; todo.push_back(u); }
+        return true;
+    };
+    if (n_walk) visited[0] = 1;
+    while (!todo.empty()) {
+        const uint32_t u = todo.back();
+        todo.pop_back();
+        if ((size_t)u + 2 > n_walk) return false;
+        const uint32_t w = wordv(f.walk, (size_t)u * 4 + 3), tag = w >> TAG_SHIFT;
+        if (tag == TAG_BOX) {
+            if (!push(w & SKIP_MASK) || !push(wordv(f.walk, (size_t)u * 4 + LINK_BOX_CHILD))) return false;
+        } else if (tag == TAG_TRI) {
+            if ((size_t)u + 3 > n_walk || !push(wordv(f.walk, (size_t)u * 4 + LINK_TRI_NEXT))) return false;
+        } else {                                   // a sphere, or a marker around a transformed mesh
+            if (!push(wordv(f.walk, (size_t)u * 4 + LINK_SPH_NEXT))) return false;
+        }
+    }
+    return true;
+}
 }  // namespace
 
 uint64_t scene_cache_key(const std::vector<rt_material>& mats, const std::vector<SceneObject>& objects,
@@ -773,8 +871,9 @@ uint64_t scene_cache_key(const std::vector<rt_material>& mats, const std::vector
     uint64_t h = 0x5254414D44ull;
     const LayoutParams lp = layout_params();
     const uint32_t leaf = (uint32_t)(std::getenv("RT_SAH_LEAF") ? std::atol(std::getenv("RT_SAH_LEAF")) : 1l);
-    const uint32_t head[9] = {(uint32_t)root_kind, (uint32_t)build_mode, lp.top_budget, lp.pair_align, lp.preorder,
-                              ENTRY_FLOATS, UNITS_END, (uint32_t)mats.size(), build_mode == RT_BUILD_SAH ? leaf : 0u};
+    const uint32_t head[10] = {(uint32_t)root_kind, (uint32_t)build_mode, lp.top_budget, lp.pair_align, lp.preorder,
+                               ENTRY_FLOATS, UNITS_END, (uint32_t)mats.size(), build_mode == RT_BUILD_SAH ? leaf : 0u,
+                               BUILDER_VERSION};
     h = hash_bytes(h, head, sizeof(head));
     if (!mats.empty()) h = hash_bytes(h, mats.data(), mats.size() * sizeof(rt_material));
     for (const SceneObject& o : objects) {
@@ -805,15 +904,16 @@ bool scene_cache_load(const std::string& path, uint64_t key, FlatScene& out) {
         if (n && std::fread(vec.data(), sizeof(vec[0]), (size_t)n, f) != (size_t)n) ok = false;
     };
     rd(fs.entries, hd.n_entries_f); rd(fs.units, hd.n_units_f); rd(fs.walk, hd.n_walk_f); rd(fs.prim_geo, hd.n_geo_f);
-    rd(fs.prim_meta, hd.n_meta); rd(fs.materials, hd.n_mat_f); rd(fs.xforms, hd.n_xform_f);
+    rd(fs.prim_meta, hd.n_meta); rd(fs.materials, hd.n_mat_f); rd(fs.xforms, hd.n_xform_f); rd(fs.prim_order, hd.n_order);
     if (ok) {
         uint64_t tail = 0;                     // the key once more behind the arrays: a complete file
         ok = std::fread(&tail, 8, 1, f) == 1 && tail == key;
     }
     std::fclose(f);
-    if (!ok || fs.units.size() < UNITS_END * 4 || fs.walk.size() < UNITS_END * 4) return false;
+    if (!ok) return false;
     fs.kinds_present = hd.kinds_present; fs.has_spheres = hd.has_spheres != 0; fs.depth = hd.depth;
     fs.ordered_ok = hd.ordered_ok != 0; fs.walk_top_units = hd.walk_top_units; fs.multi_child = hd.multi_child != 0;
+    if (!cache_arrays_sane(fs)) return false;  // the caller then builds the scene (and rewrites the file)
     out = std::move(fs);
     return true;
 }
@@ -827,14 +927,14 @@ bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& f
     hd.key = key;
     hd.n_entries_f = fl.entries.size(); hd.n_units_f = fl.units.size(); hd.n_walk_f = fl.walk.size();
     hd.n_geo_f = fl.prim_geo.size(); hd.n_meta = fl.prim_meta.size(); hd.n_mat_f = fl.materials.size();
-    hd.n_xform_f = fl.xforms.size();
+    hd.n_xform_f = fl.xforms.size(); hd.n_order = fl.prim_order.size();
     hd.kinds_present = fl.kinds_present; hd.has_spheres = fl.has_spheres ? 1u : 0u; hd.depth = fl.depth;
     hd.ordered_ok = fl.ordered_ok ? 1u : 0u; hd.walk_top_units = fl.walk_top_units; hd.multi_child = fl.multi_child ? 1u : 0u;
     bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
     auto wr = [&](const auto& vec) {
         if (ok && !vec.empty()) ok = std::fwrite(vec.data(), sizeof(vec[0]), vec.size(), f) == vec.size();
     };
-    wr(fl.entries); wr(fl.units); wr(fl.walk); wr(fl.prim_geo); wr(fl.prim_meta); wr(fl.materials); wr(fl.xforms);
+    wr(fl.entries); wr(fl.units); wr(fl.walk); wr(fl.prim_geo); wr(fl.prim_meta); wr(fl.materials); wr(fl.xforms); wr(fl.prim_order);
     ok = ok && std::fwrite(&key, 8, 1, f) == 1;
     ok = std::fclose(f) == 0 && ok;
     if (ok) ok = std::rename(tmp.c_str(), path.c_str()) == 0;
@@ -843,7 +943,8 @@ bool scene_cache_store(const std::string& path, uint64_t key, const FlatScene& f
 }
 
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out) {
+                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out,
+                             const FlatScene* reference) {
     out = FlatScene();
     if (mats.empty()) return "no materials set";
     if (mats.size() > MAT_MASK) return "too many materials";
@@ -865,7 +966,7 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
         o.prim_base = (uint32_t)prim;
         prim += o.is_mesh ? o.tris.size() : 1;
     }
-    if (prim > PRIM_ID_MASK) return "too many primitives";
+    if (prim > MAX_PRIMS) return "too many primitives";
     out.prim_geo.resize(prim * 4, 0.0f);
     out.prim_meta.resize(prim, 0);
     b.obj_box.resize(objects.size());
@@ -955,6 +1056,48 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     }
     lap("trees");
     if (out.n_entries() > SKIP_MASK) return "scene too large for 30-bit entry links";
+    {   // Primitive keys (rt_internal.hpp): the rank of a primitive is its place among the primitive
+        // entries of the REFERENCE-topology trees in pre-order, i.e. in the reference's visiting order.
+        auto word = [](const FlatScene& f, size_t i, int k) { uint32_t u; std::memcpy(&u, &f.entries[i * ENTRY_FLOATS + k], 4); return u; };
+        auto is_prim = [&](const FlatScene& f, size_t i) { const uint32_t t = word(f, i, 3) >> TAG_SHIFT; return t == TAG_TRI || t == TAG_SPH; };
+        std::vector<uint32_t> rank_of(prim, 0u);
+        if (!b.sah) {
+            uint32_t rank = 0;
+            for (size_t i = 0; i < out.n_entries(); i++)
+                if (is_prim(out, i)) rank_of[word(out, i, 7)] = rank++;
+        } else if (reference && reference->prim_order.size() == prim) {
+            for (uint32_t r = 0; r < (uint32_t)prim; r++) rank_of[reference->prim_order[r]] = r;
+        } else {                                   // another tree: the reference's trees once more, for their order alone
+            FlatScene ref;
+            Builder rb(mats, objects, ref);
+            rb.obj_box = b.obj_box; rb.xform_of = b.xform_of; rb.groups = &groups; rb.group_box = b.group_box;
+            std::vector<long> rids(groups[0].items);
+            if (root_kind == RT_ROOT_SINGLE) rb.emit_item(rids[0]);
+            else if (root_kind == RT_ROOT_LIST) { for (long it : rids) rb.emit_item(it); }
+            else rb.emit_bvh(rids.data(), rids.size(), 0, false);
+            uint32_t rank = 0;
+            for (size_t i = 0; i < ref.n_entries(); i++)
+                if (is_prim(ref, i)) rank_of[word(ref, i, 7)] = rank++;
+            lap("reference order");
+        }
+        out.prim_order.assign(prim, 0u);
+        for (uint32_t id = 0; id < (uint32_t)prim; id++) out.prim_order[rank_of[id]] = id;
+        std::vector<float> geo(out.prim_geo.size());
+        std::vector<uint32_t> meta(out.prim_meta.size());
+        for (uint32_t r = 0; r < (uint32_t)prim; r++) {
+            const uint32_t id = out.prim_order[r];
+            std::memcpy(&geo[(size_t)r * 4], &out.prim_geo[(size_t)id * 4], 16);
+            meta[r] = out.prim_meta[id];
+        }
+        out.prim_geo.swap(geo);
+        out.prim_meta.swap(meta);
+        for (size_t i = 0; i < out.n_entries(); i++)
+            if (is_prim(out, i)) {
+                const uint32_t key = prim_key(rank_of[word(out, i, 7)], (word(out, i, 3) >> TAG_SHIFT) == TAG_SPH);
+                std::memcpy(&out.entries[i * ENTRY_FLOATS + 7], &key, 4);
+            }
+        lap("primitive keys");
+    }
     annotate_children(out);
     lap("child links");
     if (!pack_units(out)) return "scene too large for 30-bit unit links";

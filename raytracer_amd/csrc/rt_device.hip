@@ -79,13 +79,25 @@ struct LaneRay {
     uint32_t i;                // cursor into the entry array
 };
 
+// TIE: the walk resolves exact ties in t by primitive key (rt_internal.hpp, "Primitive keys"); a
+// ray that has hit nothing then holds KEY_NONE, which key_result() turns into RT_MISS at the end.
+template <bool TIE = false>
 __device__ __forceinline__ void lane_ray_init(LaneRay& r, float ox, float oy, float oz, float dx, float dy,
                                               float dz, float t_max) {
     r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
     r.ix = 1.0f / dx; r.iy = 1.0f / dy; r.iz = 1.0f / dz;
     r.best_t = t_max;
-    r.best_prim = RT_MISS;
+    r.best_prim = TIE ? KEY_NONE : RT_MISS;
     r.i = 0;
+}
+template <bool TIE>
+__device__ __forceinline__ uint32_t key_result(uint32_t best_prim) {
+    return TIE && best_prim == KEY_NONE ? RT_MISS : best_prim;
+}
+// rank of the primitive a hit record names (index into prim_geo / prim_meta / prim_order)
+__device__ __forceinline__ uint32_t key_rank(uint32_t prim) {
+    const uint32_t low = prim & PRIM_ID_MASK;
+    return (prim & KEY_SPHERE) ? low : KEY_NONE - 1u - low;
 }
 
 // math.rs:149-165 on the box held in (a, b); returns the ray's next cursor.
@@ -108,6 +120,7 @@ __device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, c
 }
 
 // shape.rs:411-450 on the triangle (a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2, b.w = prim id)
+template <bool TIE = false>
 __device__ __forceinline__ void tri_step(const float4& a, const float4& b, const float4& c, LaneRay& r, float t_min) {
     const float EPS = 1.1920929e-7f;           // f32::EPSILON
     const float px = r.dy * c.z - r.dz * c.y;          // pvec = dir x v0v2
@@ -125,7 +138,8 @@ __device__ __forceinline__ void tri_step(const float4& a, const float4& b, const
             const float v = dot3(r.dx, r.dy, r.dz, qx, qy, qz) * inv_det;
             if (!(v < 0.0f || u + v > 1.0f)) {
                 const float t = dot3(c.x, c.y, c.z, qx, qy, qz) * inv_det;
-                if (t >= t_min && t < r.best_t) {  // shape.rs:297
+                // shape.rs:297; out of the reference's order a tie in t goes to the larger key
+                if (t >= t_min && (t < r.best_t || (TIE && t == r.best_t && f2u(b.w) > (r.best_prim & KEY_MASK)))) {
                     r.best_t = t;
                     r.best_prim = f2u(b.w) | (det < EPS ? PRIM_BACKFACE : 0u);
                 }
@@ -135,6 +149,7 @@ __device__ __forceinline__ void tri_step(const float4& a, const float4& b, const
 }
 
 // shape.rs:19-45 on the sphere (a.xyz = centre, b.x = radius, b.w = prim id)
+template <bool TIE = false>
 __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, LaneRay& r, float t_min) {
     const float ocx = r.ox - a.x, ocy = r.oy - a.y, ocz = r.oz - a.z;
     const float qa = dot3(r.dx, r.dy, r.dz, r.dx, r.dy, r.dz);
@@ -145,9 +160,12 @@ __device__ __forceinline__ void sphere_step(const float4& a, const float4& b, La
         const float sqrtd = sqrtf(disc);
         float root = (-half_b - sqrtd) / qa;
         bool ok = true;
-        if (root < t_min || r.best_t < root) {     // shape.rs:32-36, closed interval
+        // shape.rs:32-36, closed interval: in the reference's order a sphere at t == t_max replaces what
+        // was found before it; out of that order it does so only with the larger key
+        const bool loses_ties = TIE && !(f2u(b.w) > (r.best_prim & KEY_MASK));
+        if (root < t_min || r.best_t < root || (loses_ties && root == r.best_t)) {
             root = (-half_b + sqrtd) / qa;
-            if (root < t_min || r.best_t < root) ok = false;
+            if (root < t_min || r.best_t < root || (loses_ties && root == r.best_t)) ok = false;
         }
         if (ok) {
             r.best_t = root;
@@ -211,7 +229,7 @@ __device__ __forceinline__ void fetch_entry(const float4* __restrict__ ent, uint
 // primitive run its routine once enough of them wait (or no lane stands at a box).  Returns false
 // when no lane has an entry left.  A lane without a further entry holds TAG_END in the tag word of
 // e.a, so "at a box" and "at a primitive" are single compares whose lane masks are the ballots.
-template <bool COUNT>
+template <bool COUNT, bool TIE = false>
 __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32_t prim_wait, LaneRay& r, LaneEntry& e,
                                           float t_min, Counts& cnt) {
     const uint32_t tag = f2u(e.a.w) >> TAG_SHIFT;
@@ -239,11 +257,11 @@ __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32
             if (tag == TAG_TRI) {
                 if (COUNT) cnt.tri++;
                 const float4 c = RT_WALK_LOADS >= 3 ? e.c : ent[r.i + 2];
-                tri_step(e.a, e.b, c, r, t_min);
+                tri_step<TIE>(e.a, e.b, c, r, t_min);
                 r.i = f2u(c.w);                // the entry behind the triangle
             } else {
                 if (COUNT) cnt.sph++;
-                sphere_step(e.a, e.b, r, t_min);
+                sphere_step<TIE>(e.a, e.b, r, t_min);
                 r.i = f2u(e.b.y);              // the entry behind the sphere
             }
             if (!RT_WALK_MERGE) fetch_entry(ent, r.i, e);
@@ -317,13 +335,14 @@ __device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, 
     return true;
 }
 
-template <bool COUNT, bool OCT = false>
+template <bool COUNT, bool OCT = false, bool TIE = OCT>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                             bool valid, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
                                             float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
+    static_assert(TIE || !OCT, "the octant copies are not in the reference's order");
     LaneRay r;
-    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    lane_ray_init<TIE>(r, ox, oy, oz, dx, dy, dz, best_t);
     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(dx, dy, dz);   // the lane's copy
     // The unit array ends with TAG_END units (every copy of it does, in the octant form), which is
     // where the last entries' links lead: a lane fetches its next entry unconditionally, and a
@@ -331,9 +350,9 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
     LaneEntry e{ended, ended, ended, ended};
     if (valid) fetch_entry(ent, r.i, e);
-    while (walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt)) {}
+    while (walk_trip<COUNT, TIE>(ent, prim_wait, r, e, t_min, cnt)) {}
     best_t = r.best_t;
-    best_prim = r.best_prim;
+    best_prim = key_result<TIE>(r.best_prim);
 }
 
 // glam's Mat4::transform_point3 (w = 1) / transform_vector3 (w = 0) on the four columns at m:
@@ -371,12 +390,12 @@ __device__ __forceinline__ void xf_hit(const float4* __restrict__ xforms, const 
 // (shape.rs:454); t is the same parameter in both spaces, so best_t carries over; at LEAVE the
 // caller's ray is back.  Meshes are leaves, so one saved ray is enough.  A plain loop: every lane
 // handles whatever entry it stands at in every trip.
-template <bool COUNT>
+template <bool COUNT, bool TIE>
 __device__ __forceinline__ void closest_hit_xf(const float4* __restrict__ ent, const float4* __restrict__ xforms,
                                                bool valid, float ox, float oy, float oz, float dx, float dy, float dz,
                                                float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
-    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    lane_ray_init<TIE>(r, ox, oy, oz, dx, dy, dz, best_t);
     const float4 ended = make_float4(u2f(END_CODE_END), 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
     float4 a = ended, b = ended;
     if (valid) { a = ent[0]; b = ent[1]; }
@@ -390,11 +409,11 @@ __device__ __forceinline__ void closest_hit_xf(const float4* __restrict__ ent, c
         } else if (tag == TAG_TRI) {
             if (COUNT) cnt.tri++;
             const float4 c = ent[r.i + 2];
-            tri_step(a, b, c, r, t_min);
+            tri_step<TIE>(a, b, c, r, t_min);
             r.i = f2u(c.w);
         } else if (tag == TAG_SPH) {
             if (COUNT) cnt.sph++;
-            sphere_step(a, b, r, t_min);
+            sphere_step<TIE>(a, b, r, t_min);
             r.i = f2u(b.y);
         } else if (!done) {
             if (f2u(a.x) == END_CODE_ENTER) {
@@ -410,7 +429,7 @@ __device__ __forceinline__ void closest_hit_xf(const float4* __restrict__ ent, c
         if (!done) { a = ent[r.i]; b = ent[r.i + 1]; }
     }
     best_t = r.best_t;
-    best_prim = r.best_prim;
+    best_prim = key_result<TIE>(r.best_prim);
 }
 
 // math.rs:149-165 as a predicate (the same arithmetic as box_step)
@@ -437,7 +456,7 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
                                                     float oz, float dx, float dy, float dz, float t_min,
                                                     float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
-    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    lane_ray_init<true>(r, ox, oy, oz, dx, dy, dz, best_t);
     uint32_t sp = 0;                           // slots in use
     uint32_t top = 0;                          // next top-level entry
     bool live = false;
@@ -490,17 +509,17 @@ __device__ __forceinline__ void closest_hit_ordered(const float4* __restrict__ e
                 if (tag == TAG_TRI) {
                     if (COUNT) cnt.tri++;
                     const float4 c = ent[r.i + 2];
-                    tri_step(a, b, c, r, t_min);
+                    tri_step<true>(a, b, c, r, t_min);
                 } else {
                     if (COUNT) cnt.sph++;
-                    sphere_step(a, b, r, t_min);
+                    sphere_step<true>(a, b, r, t_min);
                 }
                 pop();
             }
         }
     }
     best_t = r.best_t;
-    best_prim = r.best_prim;
+    best_prim = key_result<true>(r.best_prim);
 }
 
 // Wide walk (opt-in; not the reference's visiting order, and not its trees): the scene's entries
@@ -615,10 +634,10 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint3
             const float4 a = pp[0], b = pp[1], c = pp[2];
             if ((f2u(a.w) >> TAG_SHIFT) == TAG_TRI) {
                 if (COUNT) cnt.tri++;
-                tri_step(a, b, c, r, t_min);
+                tri_step<true>(a, b, c, r, t_min);
             } else {
                 if (COUNT) cnt.sph++;
-                sphere_step(a, b, r, t_min);
+                sphere_step<true>(a, b, r, t_min);
             }
         }
     }
@@ -631,12 +650,12 @@ __device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes
                                                  float ox, float oy, float oz, float dx, float dy, float dz,
                                                  float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
     LaneRay r;
-    lane_ray_init(r, ox, oy, oz, dx, dy, dz, best_t);
+    lane_ray_init<true>(r, ox, oy, oz, dx, dy, dz, best_t);
     WideLane w;
     wide_lane_init(w, valid, dx, dy, dz);
     while (wide_trip<COUNT>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt)) {}
     best_t = r.best_t;
-    best_prim = r.best_prim;
+    best_prim = key_result<true>(r.best_prim);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -695,8 +714,9 @@ __device__ __forceinline__ void select_into(uint32_t& dst, uint32_t src, unsigne
     asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(dst) : "v"(src), "s"(mask));
 }
 
-// SPHERES = false drops the sphere branch for scenes that have none.
-template <bool COUNT, bool SPHERES>
+// SPHERES = false drops the sphere branch for scenes that have none.  TIE: the entry array is not in
+// the reference's order (a surface-area tree): exact ties in t go to the larger primitive key.
+template <bool COUNT, bool SPHERES, bool TIE>
 __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ ent_, uint32_t n_ent, bool valid0,
                                                    bool valid1, f32x2 ox, f32x2 oy, f32x2 oz, f32x2 dx, f32x2 dy,
                                                    f32x2 dz, float t_min, float t_max, Hit2& h, Counts& cnt) {
@@ -707,7 +727,7 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
     const bool nx1 = ix.y < 0.0f, ny1 = iy.y < 0.0f, nz1 = iz.y < 0.0f;
     const float EPS = 1.1920929e-7f;
     float bt0 = t_max, bt1 = t_max;
-    uint32_t bp0 = RT_MISS, bp1 = RT_MISS;
+    uint32_t bp0 = TIE ? KEY_NONE : RT_MISS, bp1 = bp0;
     uint32_t cur0 = valid0 ? 0u : n_ent, cur1 = valid1 ? 0u : n_ent;
     // Next entry at or after e that some lane stands on: a scalar scan that leaves the vector
     // state alone; on0 / on1 = lanes whose ray 0 / ray 1 is at that entry.  The device array ends
@@ -778,11 +798,16 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
                 // the reference's early returns (shape.rs:428-445) and acceptance test (shape.rs:297)
                 // (one ballot per comparison, combined in scalar registers: each is a single
                 // compare that writes its lane mask)
-                hit0 = on0 & __ballot(!(fabsf(det.x) < EPS)) & __ballot(!(u.x < 0.0f)) & __ballot(!(u.x > 1.0f)) &
-                       __ballot(!(v.x < 0.0f)) & __ballot(!(uv.x > 1.0f)) & __ballot(t.x >= t_min) & __ballot(t.x < bt0);
-                hit1 = on1 & __ballot(!(fabsf(det.y) < EPS)) & __ballot(!(u.y < 0.0f)) & __ballot(!(u.y > 1.0f)) &
-                       __ballot(!(v.y < 0.0f)) & __ballot(!(uv.y > 1.0f)) & __ballot(t.y >= t_min) & __ballot(t.y < bt1);
                 const uint32_t id = f2u(E[7]);
+                unsigned long long near0 = __ballot(t.x < bt0), near1 = __ballot(t.y < bt1);
+                if (TIE) {
+                    near0 |= __ballot(t.x == bt0) & __ballot(id > (bp0 & KEY_MASK));
+                    near1 |= __ballot(t.y == bt1) & __ballot(id > (bp1 & KEY_MASK));
+                }
+                hit0 = on0 & __ballot(!(fabsf(det.x) < EPS)) & __ballot(!(u.x < 0.0f)) & __ballot(!(u.x > 1.0f)) &
+                       __ballot(!(v.x < 0.0f)) & __ballot(!(uv.x > 1.0f)) & __ballot(t.x >= t_min) & near0;
+                hit1 = on1 & __ballot(!(fabsf(det.y) < EPS)) & __ballot(!(u.y < 0.0f)) & __ballot(!(u.y > 1.0f)) &
+                       __ballot(!(v.y < 0.0f)) & __ballot(!(uv.y > 1.0f)) & __ballot(t.y >= t_min) & near1;
                 nt0 = t.x; nt1 = t.y;
                 // shape.rs:424: backface = det < EPS.  An accepted hit has |det| >= EPS (and a NaN
                 // det gives a NaN t, never accepted), so there the flag is det's sign bit.
@@ -802,8 +827,11 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
                 const f32x2 r1 = (-half_b + sqrtd) / qa;
                 np0 = np1 = f2u(E[7]);
                 // shape.rs:32-36, closed interval
-                const bool b00 = (r0.x < t_min) | (bt0 < r0.x), b01 = (r1.x < t_min) | (bt0 < r1.x);
-                const bool b10 = (r0.y < t_min) | (bt1 < r0.y), b11 = (r1.y < t_min) | (bt1 < r1.y);
+                const bool lose0 = TIE && !(np0 > (bp0 & KEY_MASK)), lose1 = TIE && !(np1 > (bp1 & KEY_MASK));
+                const bool b00 = (r0.x < t_min) | (bt0 < r0.x) | (lose0 & (r0.x == bt0));
+                const bool b01 = (r1.x < t_min) | (bt0 < r1.x) | (lose0 & (r1.x == bt0));
+                const bool b10 = (r0.y < t_min) | (bt1 < r0.y) | (lose1 & (r0.y == bt1));
+                const bool b11 = (r1.y < t_min) | (bt1 < r1.y) | (lose1 & (r1.y == bt1));
                 hit0 = on0 & __ballot(!(disc.x < 0.0f) & !(b00 & b01));
                 hit1 = on1 & __ballot(!(disc.y < 0.0f) & !(b10 & b11));
                 nt0 = b00 ? r1.x : r0.x;
@@ -820,7 +848,7 @@ __device__ __forceinline__ void closest_hit_sweep2(const float4* __restrict__ en
         scan();
         E = ent[e];
     } while ((f2u(E[3]) >> TAG_SHIFT) != TAG_END);
-    h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = bp0; h.prim[1] = bp1;
+    h.t[0] = bt0; h.t[1] = bt1; h.prim[0] = key_result<TIE>(bp0); h.prim[1] = key_result<TIE>(bp1);
 }
 
 __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict__ out, size_t r, float ox, float oy,
@@ -832,9 +860,10 @@ __device__ __forceinline__ void write_hit(const DevScene& sc, rt_hit* __restrict
         h.p[0] = h.p[1] = h.p[2] = 0.0f; h.n[0] = h.n[1] = h.n[2] = 0.0f;
         h.front_face = 0; h.mat = 0;
     } else {
-        const uint32_t id = prim & PRIM_ID_MASK;
-        const float4 g = geo[id];
-        const uint32_t meta = sc.prim_meta[id];
+        const uint32_t rank = key_rank(prim);
+        const float4 g = geo[rank];
+        const uint32_t meta = sc.prim_meta[rank];
+        const uint32_t id = sc.prim_order[rank];       // the id the caller knows the primitive by
         float nx, ny, nz;
         if (meta & META_SPHERE) {                      // shape.rs:41
             const float sx = ox + dx * t, sy = oy + dy * t, sz = oz + dz * t;
@@ -866,7 +895,7 @@ extern __shared__ uint32_t lds_stack[];
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
 //        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
 //        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only)
-template <bool COUNT, int SWEEP>
+template <bool COUNT, int SWEEP, bool TIE>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
             rt_hit* __restrict__ out, Totals* partials) {
@@ -884,7 +913,7 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             if (va) for (int k = 0; k < 3; k++) { o0[k] = rays[ra * 6 + k]; d0[k] = rays[ra * 6 + 3 + k]; }
             if (vb) for (int k = 0; k < 3; k++) { o1[k] = rays[rb * 6 + k]; d1[k] = rays[rb * 6 + 3 + k]; }
             Hit2 h;
-            closest_hit_sweep2<COUNT, SWEEP == 2>(ent, sc.n_entries, va, vb, f32x2{o0[0], o1[0]}, f32x2{o0[1], o1[1]},
+            closest_hit_sweep2<COUNT, SWEEP == 2, TIE>(ent, sc.n_entries, va, vb, f32x2{o0[0], o1[0]}, f32x2{o0[1], o1[1]},
                                       f32x2{o0[2], o1[2]}, f32x2{d0[0], d1[0]}, f32x2{d0[1], d1[1]},
                                       f32x2{d0[2], d1[2]}, t_min, t_max, h, cnt);
             if (va) write_hit(sc, out, ra, o0[0], o0[1], o0[2], d0[0], d0[1], d0[2], h.t[0], h.prim[0]);
@@ -910,13 +939,13 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 9)
-                closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+                closest_hit_xf<COUNT, TIE>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 11)
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid,
                                         ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+                closest_hit<COUNT, false, TIE>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             if (valid) write_hit(sc, out, r, ox, oy, oz, dx, dy, dz, t, prim);
         }
     }
@@ -1107,7 +1136,7 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
         Lbuf[slot] = make_float4(c.x * r, c.y * gg, c.z * bb, 0.0f);
         return 7u;
     }
-    const uint32_t mk = prim_meta[prim & PRIM_ID_MASK];
+    const uint32_t mk = prim_meta[key_rank(prim)];
     const uint32_t k = (mk >> KIND_SHIFT) & 3u;
     if (k == RT_MAT_EMISSIVE) {                            // emit, no scatter (material.rs:126-130)
         const float4 c = C[i];
@@ -1151,7 +1180,7 @@ __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 // (finish_ray + queueing) and take the next rays of the segment.  Every ray is still walked by one
 // lane in the reference's order; only which lane and when changes, and nothing downstream depends
 // on that (queues are compacted per kind, radiance is stored per path slot).
-template <bool COUNT, bool OCT = false, bool SPLIT = false>
+template <bool COUNT, bool TIE, bool OCT = false, bool SPLIT = false>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                              uint32_t refill_min, const SplitCfg& sp, const float4* __restrict__ mats,
                                              const uint32_t* __restrict__ prim_meta, const float4* __restrict__ A,
@@ -1161,8 +1190,10 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                                              float4* __restrict__ Lbuf, uint32_t base, uint32_t n,
                                              uint32_t last_depth, float t_min, float sky_intensity, uint32_t& n0,
                                              uint32_t& n1, uint32_t& n2, Counts& cnt) {
+    static_assert(TIE || !OCT, "the octant copies are not in the reference's order");
+    static_assert(!(TIE && SPLIT), "the split walk is a reference-order form");
     LaneRay r;
-    lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
+    lane_ray_init<TIE>(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
     bool has_ray = false;
     uint32_t next = 0;                         // rays of the segment handed out so far (wave-uniform)
@@ -1178,8 +1209,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
             uint32_t kind = 7u;
             if (has_ray && !live) {
-                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t, r.best_prim,
-                                  last_depth, sky_intensity);
+                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t,
+                                  key_result<TIE>(r.best_prim), last_depth, sky_intensity);
                 has_ray = false;
             }
             uint32_t pos;
@@ -1196,7 +1227,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                 if (!live && j < n) {
                     ray_i = base + j;
                     const float4 ra = A[ray_i], rb = B[ray_i];
-                    lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
+                    lane_ray_init<TIE>(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
@@ -1208,7 +1239,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
             }
         }
         if (SPLIT) walk_trip_split<COUNT>(ent, sp, prim_wait, r, e, t_min, cnt);
-        else walk_trip<COUNT>(ent, prim_wait, r, e, t_min, cnt);
+        else walk_trip<COUNT, TIE>(ent, prim_wait, r, e, t_min, cnt);
     }
 }
 
@@ -1226,7 +1257,7 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
                                              uint32_t n, uint32_t last_depth, float t_min, float sky_intensity,
                                              uint32_t& n0, uint32_t& n1, uint32_t& n2, Counts& cnt) {
     LaneRay r;
-    lane_ray_init(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
+    lane_ray_init<true>(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     WideLane w;
     wide_lane_init(w, false, 1.0f, 1.0f, 1.0f);
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
@@ -1239,8 +1270,8 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
             uint32_t kind = 7u;
             if (has_ray && !live) {
-                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t, r.best_prim,
-                                  last_depth, sky_intensity);
+                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t,
+                                  key_result<true>(r.best_prim), last_depth, sky_intensity);
                 has_ray = false;
             }
             uint32_t pos;
@@ -1257,7 +1288,7 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
                 if (!live && j < n) {
                     ray_i = base + j;
                     const float4 ra = A[ray_i], rb = B[ray_i];
-                    lane_ray_init(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
+                    lane_ray_init<true>(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
                     wide_lane_init(w, true, rb.x, rb.y, rb.z);
                     slot = f2u(ra.w);
                     has_ray = true;
@@ -1273,7 +1304,7 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
 // Closest hit for the n live rays of the segment at `base`: terminates paths (sky, emitter, depth
 // cap) or records the hit and queues the ray under its material kind; n0 / n1 / n2 return the
 // queue lengths.  Whole wave, converged.
-template <bool COUNT, int SWEEP>
+template <bool COUNT, int SWEEP, bool TIE>
 __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* __restrict__ A,
                                               const float4* __restrict__ B, const float4* __restrict__ C,
                                               uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -1304,7 +1335,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             if (va) { a0 = A[ia]; b0 = B[ia]; }
             if (vb) { a1 = A[ib]; b1 = B[ib]; }
             Hit2 h;
-            closest_hit_sweep2<COUNT, SWEEP == 2>(ent, sc.n_entries, va, vb, f32x2{a0.x, a1.x}, f32x2{a0.y, a1.y},
+            closest_hit_sweep2<COUNT, SWEEP == 2, TIE>(ent, sc.n_entries, va, vb, f32x2{a0.x, a1.x}, f32x2{a0.y, a1.y},
                                       f32x2{a0.z, a1.z}, f32x2{b0.x, b1.x}, f32x2{b0.y, b1.y}, f32x2{b0.z, b1.z},
                                       t_min, t_max, h, cnt);
             uint32_t ka = 7u, kb = 7u;
@@ -1316,11 +1347,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             enqueue(kb, ib);
         }
     } else if (SWEEP == 5 || SWEEP == 6) {
-        walk_segment<COUNT>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
+        walk_segment<COUNT, TIE>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
                             sc.refill, SplitCfg{nullptr, 0u, 0u}, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base,
                             n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 10) {
-        walk_segment<COUNT, false, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, sc.refill,
+        walk_segment<COUNT, false, false, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, sc.refill,
                                          SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, mats, sc.prim_meta,
                                          A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
                                          n1, n2, cnt);
@@ -1329,7 +1360,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                             lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
                             q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 8) {
-        walk_segment<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
+        walk_segment<COUNT, true, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
                                   mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
                                   sky_intensity, n0, n1, n2, cnt);
     } else {
@@ -1346,17 +1377,17 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                            lds_stack + (threadIdx.x >> 6) * sc.stack_depth * 64u, lane, valid, a.x,
                                            a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 4)
-                closest_hit<COUNT>((const float4*)lds_stack, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit<COUNT, false, TIE>((const float4*)lds_stack, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 9)
-                closest_hit_xf<COUNT>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit_xf<COUNT, TIE>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 11)
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
                                         b.x, b.y, b.z, t_min, t, prim, cnt);
             else
-                closest_hit<COUNT>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+                closest_hit<COUNT, false, TIE>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
                 kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                   sky_intensity);
@@ -1382,7 +1413,7 @@ __device__ __forceinline__ void write_stamp(uint32_t stamp_slot, uint32_t seg, u
 #define RT_STAMP_ARG
 #endif
 
-template <bool COUNT, int SWEEP>
+template <bool COUNT, int SWEEP, bool TIE>
 __global__ void __launch_bounds__(RT_WAVE) __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __restrict__ B,
         const float4* __restrict__ C, uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -1397,7 +1428,7 @@ k_trace(DevScene sc, BatchGeom g, const float4* __restrict__ A, const float4* __
     const uint32_t n = segcnt[seg];
     uint32_t n0, n1, n2;
     Counts cnt{0, 0, 0};
-    trace_segment<COUNT, SWEEP>(sc, A, B, C, hits, q0, q1, q2, Lbuf, seg * g.seg_len, n, lane, last_depth, t_min,
+    trace_segment<COUNT, SWEEP, TIE>(sc, A, B, C, hits, q0, q1, q2, Lbuf, seg * g.seg_len, n, lane, last_depth, t_min,
                                 sky_intensity, n0, n1, n2, cnt);
     if (lane == 0) {
         qcnt[seg] = n0;
@@ -1437,7 +1468,7 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
             const float4 a = A[i], b = B[i], c = C[i];
             const uint2 h = hits[i];
             const float t = u2f(h.x);
-            const uint32_t id = h.y & PRIM_ID_MASK;
+            const uint32_t id = key_rank(h.y);
             const uint32_t meta = sc.prim_meta[id];
             const float4 g = geo[id];
             const float4 m0 = mats[2 * (meta & MAT_MASK)];
@@ -1581,7 +1612,7 @@ __device__ __forceinline__ void stage_fence() {
 #ifndef RT_LDS_BLOCK
 #define RT_LDS_BLOCK 512
 #endif
-template <int SWEEP>
+template <int SWEEP, bool TIE>
 __global__ void __launch_bounds__(SWEEP == 4 || SWEEP == 6 || SWEEP == 10 ? RT_LDS_BLOCK : RT_WAVE)
     __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
@@ -1612,10 +1643,10 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
         stage_fence();
         uint32_t n0, n1, n2;
 #ifdef RT_UTIL
-        trace_segment<true, SWEEP>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
+        trace_segment<true, SWEEP, TIE>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
                                    t_min, sky_intensity, n0, n1, n2, cnt);
 #else
-        trace_segment<false, SWEEP>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
+        trace_segment<false, SWEEP, TIE>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
                                     t_min, sky_intensity, n0, n1, n2, cnt);
 #endif
         if (last) break;
@@ -1702,21 +1733,27 @@ int launch_trace_walk(const LaunchCfg&, const DevScene&, const BatchGeom&, const
 int launch_path_walk(const LaunchCfg&, const DevScene&, const rt_camera&, const BatchGeom&, uint64_t seed,
                      const RenderBuffers&, uint32_t max_bounces, float t_min, float sky_intensity);
 
-#define RT_TRACE_API(CNT, SWP)                                                                          \
-    hipLaunchKernelGGL((k_trace_api<CNT, SWP>), dim3(grid), dim3(RT_BLOCK), lds, st, sc, (const float*)d_rays, n, \
+// (the _T forms take the tie rule as an argument; the plain ones pick it by the scene's flag: the forms
+// that exist in the reference's order and out of it -- walks and sweeps over either tree)
+#define RT_TRACE_API_T(CNT, SWP, TIE)                                                                   \
+    hipLaunchKernelGGL((k_trace_api<CNT, SWP, TIE>), dim3(grid), dim3(RT_BLOCK), lds, st, sc, (const float*)d_rays, n, \
                        t_min, t_max, (rt_hit*)d_hits, d_counts)
-#define RT_TRACE(CNT, SWP)                                                                              \
-    hipLaunchKernelGGL((k_trace<CNT, SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
+#define RT_TRACE_API(CNT, SWP) do { if (sc.tie) RT_TRACE_API_T(CNT, SWP, true); else RT_TRACE_API_T(CNT, SWP, false); } while (0)
+#define RT_TRACE_T(CNT, SWP, TIE)                                                                       \
+    hipLaunchKernelGGL((k_trace<CNT, SWP, TIE>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, (const float4*)rb.cur.A, \
                        (const float4*)rb.cur.B, (const float4*)rb.cur.C, (uint2*)rb.hits, rb.queue[0],  \
                        rb.queue[1], rb.queue[2], (float4*)rb.Lbuf, segcnt, rb.qcnt, rb.totals,          \
                        last_depth ? 1u : 0u, t_min, sky_intensity RT_STAMP_ARG)
-#define RT_PATH(SWP)                                                                                    \
-    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
+#define RT_TRACE(CNT, SWP) do { if (sc.tie) RT_TRACE_T(CNT, SWP, true); else RT_TRACE_T(CNT, SWP, false); } while (0)
+#define RT_PATH_T(SWP, TIE)                                                                             \
+    hipLaunchKernelGGL((k_path<SWP, TIE>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
-#define RT_PATH_LDS(SWP)                                                                                \
-    hipLaunchKernelGGL((k_path<SWP>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
+#define RT_PATH(SWP) do { if (sc.tie) RT_PATH_T(SWP, true); else RT_PATH_T(SWP, false); } while (0)
+#define RT_PATH_LDS_T(SWP, TIE)                                                                         \
+    hipLaunchKernelGGL((k_path<SWP, TIE>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
                        bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
                        sky_intensity RT_STAMP_ARG)
+#define RT_PATH_LDS(SWP) do { if (sc.tie) RT_PATH_LDS_T(SWP, true); else RT_PATH_LDS_T(SWP, false); } while (0)
 #ifdef RT_STAMPS
 static uint32_t stamped_launches = 0;
 #endif
@@ -1742,10 +1779,10 @@ int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* 
                           float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const size_t lds = stack_bytes(sc, RT_BLOCK / 64);
-    if (sc.wide) { if (count) RT_TRACE_API(true, 11); else RT_TRACE_API(false, 11); }
+    if (sc.wide) { if (count) RT_TRACE_API_T(true, 11, true); else RT_TRACE_API_T(false, 11, true); }
     else if (sc.n_xforms) { if (count) RT_TRACE_API(true, 9); else RT_TRACE_API(false, 9); }
-    else if (sc.octant) { if (count) RT_TRACE_API(true, 7); else RT_TRACE_API(false, 7); }
-    else if (sc.ordered) { if (count) RT_TRACE_API(true, 3); else RT_TRACE_API(false, 3); }
+    else if (sc.octant) { if (count) RT_TRACE_API_T(true, 7, true); else RT_TRACE_API_T(false, 7, true); }
+    else if (sc.ordered) { if (count) RT_TRACE_API_T(true, 3, true); else RT_TRACE_API_T(false, 3, true); }
     else { if (count) RT_TRACE_API(true, 0); else RT_TRACE_API(false, 0); }
     return check_launch();
 }
@@ -1758,10 +1795,10 @@ int launch_trace_walk(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom&
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.wide) { if (count) RT_TRACE(true, 11); else RT_TRACE(false, 11); }
+    if (sc.wide) { if (count) RT_TRACE_T(true, 11, true); else RT_TRACE_T(false, 11, true); }
     else if (sc.n_xforms) { if (count) RT_TRACE(true, 9); else RT_TRACE(false, 9); }
-    else if (sc.octant) { if (count) RT_TRACE(true, 7); else RT_TRACE(false, 7); }
-    else if (sc.ordered) { if (count) RT_TRACE(true, 3); else RT_TRACE(false, 3); }
+    else if (sc.octant) { if (count) RT_TRACE_T(true, 7, true); else RT_TRACE_T(false, 7, true); }
+    else if (sc.ordered) { if (count) RT_TRACE_T(true, 3, true); else RT_TRACE_T(false, 3, true); }
     else { if (count) RT_TRACE(true, 0); else RT_TRACE(false, 0); }
     return check_launch();
 }
@@ -1774,20 +1811,20 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.wide) { if (sc.refill) RT_PATH(12); else RT_PATH(11); return check_launch(); }
+    if (sc.wide) { if (sc.refill) RT_PATH_T(12, true); else RT_PATH_T(11, true); return check_launch(); }
     if (sc.n_xforms) { RT_PATH(9); return check_launch(); }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
         if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
         return check_launch();
     }
-    if (sc.split_top && sc.refill && !sc.ordered && !sc.octant) {
+    if (sc.split_top && sc.refill && !sc.ordered && !sc.octant && !sc.tie) {
         const size_t bytes = (size_t)sc.split_top * 16u;
-        RT_PATH_LDS(10);
+        RT_PATH_LDS_T(10, false);
         return check_launch();
     }
-    if (sc.octant) { if (sc.refill) RT_PATH(8); else RT_PATH(7); }
-    else if (sc.ordered) RT_PATH(3);
+    if (sc.octant) { if (sc.refill) RT_PATH_T(8, true); else RT_PATH_T(7, true); }
+    else if (sc.ordered) RT_PATH_T(3, true);
     else if (sc.refill) RT_PATH(5);
     else RT_PATH(0);
     return check_launch();

@@ -23,10 +23,27 @@ namespace rtamd {
 // One entry = four float4 (64 bytes, so that an entry is one aligned 64-byte fetch: a single
 // s_load_dwordx16 for the wave sweep, one cache sector for the per-lane walk):
 //   box      a = (min.xyz , TAG_BOX<<30 | skip)   b = (max.xyz , 0)
-//   triangle a = (v0.xyz  , TAG_TRI<<30)          b = (e1.xyz  , prim_id)   c = (e2.xyz, 0)
-//   sphere   a = (c.xyz   , TAG_SPH<<30)          b = (r, 0, 0, prim_id)
+//   triangle a = (v0.xyz  , TAG_TRI<<30)          b = (e1.xyz  , prim key)  c = (e2.xyz, 0)
+//   sphere   a = (c.xyz   , TAG_SPH<<30)          b = (r, 0, 0, prim key)
 // The fourth float4 is padding.  e1 = v1 - v0 and e2 = v2 - v0 are the reference's v0v1 / v0v2
 // (shape.rs:417-418) computed once instead of per test.
+//
+// Primitive keys.  Inside the library a primitive is not named by its id (its place in the order
+// the caller added it) but by a key made from its RANK, its place in the order the reference's
+// recursion visits the primitives (the pre-order of the reference-topology trees, whatever tree
+// the scene is traced with):
+//   triangle  key = KEY_NONE - 1 - rank        sphere  key = KEY_SPHERE | rank
+// The per-primitive tables (prim_geo, prim_meta) are indexed by rank, and FlatScene::prim_order
+// maps rank -> id for the one place that reports ids (rt_trace's hit records).  The keys make the
+// reference's resolution of EXACT ties in t independent of the visiting order.  In the reference
+// a triangle replaces the closest hit only when t < t_max (shape.rs:297) and a sphere when
+// root <= t_max (shape.rs:32-36), so among the primitives that tie at the smallest t the winner
+// is the sphere visited last if there is one, else the triangle visited first -- the primitive
+// of the LARGEST key.  A walk that visits in another order (another tree, nearer child first)
+// therefore accepts a primitive when t < best_t, or when t == best_t and its key is larger than
+// the key in hand; KEY_NONE ("nothing hit yet") lies above every triangle and below every sphere,
+// which is the reference's behaviour at t == t_max.  The reference-order walks need none of that
+// and keep the plain comparisons.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ENTRY_FLOATS = 16;
 constexpr uint32_t TAG_BOX = 0, TAG_TRI = 1, TAG_SPH = 2;
@@ -54,13 +71,19 @@ constexpr uint32_t UNITS_END = 4;
 constexpr uint32_t KIND_SHIFT = 28;
 constexpr uint32_t MAT_MASK = (1u << KIND_SHIFT) - 1u;
 constexpr uint32_t PRIM_BACKFACE = 1u << 31;       // flag in the compact hit record
-constexpr uint32_t PRIM_ID_MASK = 0x3FFFFFFFu;
+constexpr uint32_t PRIM_ID_MASK = 0x3FFFFFFFu;      // the rank bits of a key
+constexpr uint32_t KEY_SPHERE = 1u << 30;
+constexpr uint32_t KEY_NONE = 0x3FFFFFFFu;          // no hit yet (tie-aware walks); ranks stay below KEY_NONE - 1
+constexpr uint32_t KEY_MASK = 0x7FFFFFFFu;          // a hit record's key (bit 31: PRIM_BACKFACE)
+constexpr uint32_t MAX_PRIMS = KEY_NONE - 1u;
+inline uint32_t prim_key(uint32_t rank, bool sphere) { return sphere ? (KEY_SPHERE | rank) : (KEY_NONE - 1u - rank); }
 constexpr uint32_t META_SPHERE = 1u << 31;         // flag in prim_meta
 
 struct FlatScene {
     std::vector<float> entries;        // ENTRY_FLOATS per entry
-    std::vector<float> prim_geo;       // 4 floats per primitive: tri (unit n0, 0) / sphere (c, r)
-    std::vector<uint32_t> prim_meta;   // material index | material kind << KIND_SHIFT | META_SPHERE
+    std::vector<float> prim_geo;       // 4 floats per primitive, by rank: tri (unit n0, 0) / sphere (c, r)
+    std::vector<uint32_t> prim_meta;   // by rank: material index | material kind << KIND_SHIFT | META_SPHERE
+    std::vector<uint32_t> prim_order;  // rank -> primitive id (see "Primitive keys" above)
     std::vector<float> materials;      // 8 floats per material: rgb, param, kind, flags, 0, 0
     // 32 floats per transformed mesh: Mesh.transform then Mesh.inverse_transform (shape.rs:212-213),
     // column-major.  A triangle of such a mesh keeps its raw first-vertex normal in prim_geo and the
@@ -114,8 +137,12 @@ struct SceneGroup {
 // otherwise the error message.
 // build_mode RT_BUILD_SAH replaces the reference's median split inside meshes by a binned
 // surface-area-heuristic split (same entry format, same box padding, one triangle per leaf).
+// `reference`: the same scene flattened with RT_BUILD_REFERENCE, when the caller has it: a build
+// of another mode takes the primitives' ranks from it instead of building the reference's trees
+// once more for their order.
 std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<SceneObject>& objects,
-                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out);
+                             const std::vector<SceneGroup>& groups, int root_kind, int build_mode, FlatScene& out,
+                             const FlatScene* reference = nullptr);
 
 // Binary scene cache: the flattened arrays of a scene on disk, keyed by what they were built from.
 // scene_cache_key() hashes the description (materials, every sphere and triangle, transforms,
@@ -187,8 +214,11 @@ struct DevScene {
     const void* walk;         // float4[n_walk + UNITS_END]: linked units in locality order (reference-order per-lane walks)
     uint32_t n_walk;
     uint32_t walk_top_units;  // the first units of `walk` hold the top levels of the trees, breadth first
-    const void* prim_geo;     // float4[n_prims]
-    const uint32_t* prim_meta;
+    const void* prim_geo;     // float4[n_prims], by rank
+    const uint32_t* prim_meta; // by rank
+    const uint32_t* prim_order;   // rank -> primitive id
+    uint32_t tie;             // 1: the walk does not visit in the reference's order (another tree, or nearer child
+                              // first): exact ties in t are resolved by primitive key
     const void* materials;    // float4[2 * n_mats]
     uint32_t n_entries;
     uint32_t n_units;

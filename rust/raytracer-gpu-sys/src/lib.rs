@@ -108,6 +108,7 @@ extern "C" {
     pub fn rt_scene_num_prims(scene: *const rt_scene) -> usize;
     pub fn rt_scene_num_entries(scene: *const rt_scene) -> usize;
     pub fn rt_scene_get_entries(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
+    pub fn rt_scene_get_prim_order(scene: *const rt_scene, out: *mut u32, n: usize) -> c_int;
     pub fn rt_scene_num_units(scene: *const rt_scene) -> usize;
     pub fn rt_scene_get_units(scene: *const rt_scene, out: *mut f32, n_floats: usize) -> c_int;
     pub fn rt_scene_num_walk_units(scene: *const rt_scene) -> usize;

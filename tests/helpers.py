@@ -201,3 +201,64 @@ def unpack_0rgb(packed, h, w):
 def block_means(a, k):
     h, w, c = a.shape
     return a.reshape(h // k, k, w // k, k, c).mean(axis=(1, 3))
+
+
+def tie_scene(ob, seed=7, n_random_rays=4000):
+    """A scene built to produce EXACT ties in t, the one case where the visiting order decides which
+    primitive the reference reports (shape.rs:32-36: a sphere replaces the hit at root <= t_max,
+    shape.rs:297: a triangle only at t < t_max), and rays that find them.  Returns (materials,
+    objects, rays, dyadic) where rays[dyadic:] are the hand-placed rays of the last paragraph.
+
+    - triangles that occur several times (inside one mesh, across meshes, with other materials and
+      normals): bit-identical t on every ray that hits them;
+    - spheres that occur several times, as neighbours and far apart in the object list;
+    - a sphere and triangles placed so that rays with small dyadic coordinates meet both at exactly
+      the same t (all the arithmetic of both tests is exact there), the sphere before the triangles
+      in the object list in one group and behind them in another."""
+    from_rng = np.random.default_rng(seed)
+    mats = np.zeros(6, dtype=ob.material_dt)
+    mats["kind"] = [ob.LAMBERT, ob.METAL, ob.DIELECTRIC, ob.EMISSIVE, ob.LAMBERT, ob.METAL]
+    mats["rgb"] = from_rng.uniform(0.2, 1.0, (6, 3)).astype(np.float32)
+    mats["param"] = [0.0, 0.3, 1.5, 0.0, 0.0, 1.0]
+    base = random_mesh(ob, from_rng, 24, extent=3.0, size=2.0)
+    twice = np.concatenate([base, base[::-1]])                 # every triangle twice inside one mesh
+    twice["mat"] = np.arange(len(twice)) % 6
+    again = base[5:17].copy()                                  # and some of them in a second mesh
+    again["n0"] = -again["n0"]
+    again["mat"] = (again["mat"] + 1) % 6
+    sp = np.zeros(5, dtype=ob.sphere_dt)
+    sp["c"] = from_rng.uniform(-3, 3, (5, 3)).astype(np.float32)
+    sp["r"] = from_rng.uniform(0.4, 1.2, 5).astype(np.float32)
+    sp["mat"] = [0, 1, 2, 4, 5]
+    sp_again = sp[[3, 1, 1, 0]].copy()
+    sp_again["mat"] = [1, 2, 0, 5]
+
+    def quad(z, x0, x1, y0, y1, mat):
+        tr = np.zeros(2, dtype=ob.triangle_dt)
+        tr["p"][0] = [[x0, y0, z], [x1, y0, z], [x1, y1, z]]
+        tr["p"][1] = [[x0, y0, z], [x1, y1, z], [x0, y1, z]]
+        tr["n0"] = [0.0, 0.0, 1.0]
+        tr["mat"] = mat
+        return tr
+
+    # unit spheres whose pole a ray reaches at the t at which it crosses the plane the pole lies in
+    def pole_group(cx, cy, sphere_first):
+        s = np.zeros(1, dtype=ob.sphere_dt)
+        s["c"] = [cx, cy, 0.0]
+        s["r"] = 1.0
+        s["mat"] = 2
+        q = np.concatenate([quad(-1.0, cx - 2, cx + 2, cy - 2, cy + 2, 0), quad(-1.0, cx - 2, cx + 2, cy - 2, cy + 2, 1)])
+        return [("spheres", s), ("mesh", q)] if sphere_first else [("mesh", q), ("spheres", s)]
+
+    objects = [("spheres", sp[:3]), ("mesh", twice), ("spheres", sp_again), ("mesh", again), ("spheres", sp[3:])]
+    objects += pole_group(16.0, 0.0, True) + pole_group(32.0, 8.0, False)
+    rays = random_rays(ob, seed + 1, n_random_rays, -4.0, 4.0)
+    poles = []
+    for cx, cy in ((16.0, 0.0), (32.0, 8.0)):
+        for dz in (1.0, 2.0, 0.5, 4.0):                        # straight down the pole: t = 4 / dz, 6 / dz behind
+            poles.append(((cx, cy, -5.0), (0.0, 0.0, dz)))
+            poles.append(((cx, cy, 5.0), (0.0, 0.0, -dz)))
+    dy = np.zeros(len(poles), dtype=ob.ray_dt)
+    dy["o"] = [p[0] for p in poles]
+    dy["d"] = [p[1] for p in poles]
+    return mats, objects, np.concatenate([rays, dy]), len(rays)

@@ -367,11 +367,11 @@ def test_headless_main_writes_the_library_frame(rt, ob, ctx, tmp_path):
 
     got, _ = run()
     assert np.array_equal(got, want_rgb)
-    # the opt-in wide walk through the C ABI (its tree collapsed on the host, or built on the GPU): the same
-    # frame and the same rays unless a tie in t goes to another primitive
+    # the wide walk through the C ABI (its tree collapsed on the host, or built on the GPU): the same
+    # rays and the same frame
     for flag in ("--wide", "--wide-device"):
-        wide, _ = run(flag, same_rays=False)
-        assert (wide != want_rgb).any(axis=-1).mean() <= 1e-3
+        wide, _ = run(flag)
+        assert np.array_equal(wide, want_rgb)
     prog, text = run("--progressive")
     assert "block events" in text
     assert np.abs(prog.astype(int) - want_rgb.astype(int)).max() <= 1

@@ -62,14 +62,14 @@ def test_soup_closest_hits_match_oracle(rt, ob, ctx, soup):
     assert_hits_equal(world.scene.trace(rays[:200_000]), want[:200_000])
 
 
-def _same_up_to_ties(rt, got, want, label):
+def _same_hits(rt, got, want, label):
     nan = np.isnan(want["t"])
     assert np.array_equal(got["prim_id"] == rt.MISS, want["prim_id"] == rt.MISS)
     hit = (want["prim_id"] != rt.MISS) & ~nan
     assert np.array_equal(got["t"][hit].view(np.uint32), want["t"][hit].view(np.uint32)), f"{label}: t differs"
     ties = int((got["prim_id"] != want["prim_id"]).sum())
-    print(f"{label}: {len(want)} rays, t bit-identical, {ties} exact ties resolved to another primitive")
-    assert ties <= 1e-4 * len(want)
+    print(f"{label}: {len(want)} rays, t bit-identical, {ties} primitives differ")
+    assert ties == 0
 
 
 @pytest.mark.parametrize("walk", ["ordered", "octant", "wide"])
@@ -77,7 +77,7 @@ def test_soup_near_first_walks(rt, ob, ctx, soup, walk):
     world, osc, rays, want = soup
     world.scene.set_traversal({"ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[walk])
     try:
-        _same_up_to_ties(rt, world.scene.trace(rays), want, f"{walk} walk")
+        _same_hits(rt, world.scene.trace(rays), want, f"{walk} walk")
     finally:
         world.scene.set_traversal(rt.TRAVERSAL_AUTO)
 
@@ -87,7 +87,7 @@ def test_soup_wide_tree_built_on_the_gpu(rt, ob, ctx, soup):
     world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
     world.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
     world.scene.set_traversal(rt.TRAVERSAL_WIDE)
-    _same_up_to_ties(rt, world.scene.trace(rays), want, "wide tree built on the GPU")
+    _same_hits(rt, world.scene.trace(rays), want, "wide tree built on the GPU")
     world.close()
 
 
@@ -101,7 +101,7 @@ def test_soup_sah_tree(rt, ob, ctx, soup):
     for mode, label in ((rt.TRAVERSAL_PER_LANE, "SAH tree, per-lane walk"), (rt.TRAVERSAL_OCTANT, "SAH tree, octant walk"),
                         (rt.TRAVERSAL_WIDE, "SAH tree collapsed to eight-child nodes, wide walk")):
         world.scene.set_traversal(mode)
-        _same_up_to_ties(rt, world.scene.trace(rays), want, label)
+        _same_hits(rt, world.scene.trace(rays), want, label)
     world.close()
 
 
@@ -164,8 +164,10 @@ def test_soup_full_size_frame(rt, ob, ctx):
           f"oracle {mean_cpu:.5f}; rays per path gpu {st['rays_traced'] / st['paths']:.4f} oracle {ost['rays'] / ost['paths']:.4f}")
     assert abs(mean_gpu - mean_cpu) <= 0.03 * mean_cpu
     assert abs(st["rays_traced"] / st["paths"] - ost["rays"] / ost["paths"]) < 0.03
-    # the same frame through the opt-in wide walk, its tree collapsed on the host, then built on the GPU:
-    # the same RNG keys, so a path changes only where a tie in t goes to another primitive
+    # the same frame through the wide walk, its tree collapsed on the host, then built on the GPU: the same
+    # RNG keys, so a path changes only where a box of the reference's tree, closed by rounding in front of a
+    # primitive whose own test accepts the ray, has no counterpart among the wide tree's boxes (which enclose
+    # the reference's): a few rays in 10^9, counted here
     world.scene.set_traversal(rt.TRAVERSAL_WIDE)
     wide, st_w = render()
     world.close()
