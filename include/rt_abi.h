@@ -112,6 +112,8 @@ typedef struct {
 enum { RT_FORM_SWEEP = 0, RT_FORM_WALK = 1, RT_FORM_WALK_LDS = 2, RT_FORM_WALK_REFILL = 3,
        RT_FORM_WALK_LDS_REFILL = 4, RT_FORM_ORDERED = 5, RT_FORM_OCTANT = 6, RT_FORM_OCTANT_REFILL = 7,
        RT_FORM_WIDE = 8, RT_FORM_WIDE_REFILL = 9 };
+/* which of the scene's trees the render walked (rt_stats.tree) */
+enum { RT_TREE_REFERENCE = 0, RT_TREE_SAH = 1 };
 
 typedef struct {
     uint64_t rays_traced;    /* closest-hit queries, i.e. executions of main.rs:46 */
@@ -125,7 +127,25 @@ typedef struct {
     double ms_reduce;        /* rt_render_multi: host wall time of the sum-reduce (and the copy to the host) */
     uint32_t n_devices;      /* GPUs that rendered (1 for rt_render / rt_render_device) */
     uint32_t kernel_form;    /* RT_FORM_* the render ran (device 0's, for rt_render_multi) */
+    uint32_t tree;           /* RT_TREE_* the render walked (device 0's, for rt_render_multi) */
+    uint32_t rccl_ranks;     /* rt_render_multi: ranks of the RCCL communicator the reduce ran on (ncclCommCount);
+                                0 when the frames were added without RCCL */
+    double ms_kernel_span;   /* with RT_RENDER_PROFILE: from the start of the first to the end of the last of the
+                                kernels that hold the closest hit, over all pipelines (they overlap, so this, not
+                                their sum ms_trace, is what the call's wall time contains) */
+    double ms_render_min;    /* rt_render_multi: the fastest GPU's render time (ms_render is the slowest's) */
+    uint32_t slowest_device; /* rt_render_multi: index into dev_ids of the GPU whose render took longest */
+    uint32_t reduce_mode;    /* rt_render_multi: RT_REDUCE_* the frames were combined with */
+    double shader_clock_ghz; /* with RT_RENDER_PROFILE (not STAGED): the shader clock the per-batch kernels ran at,
+                                from the cycle counter and the constant-rate 100 MHz counter read by one wave of
+                                every launch at its start and at its end (0: not measured) */
+    /* rt_render_multi: per GPU (the first RT_STATS_MAX_DEVICES of the context, in dev_ids order) the render
+     * time, the RT_FORM_* and the RT_TREE_* of its share */
+    float device_ms_render[16];
+    uint8_t device_form[16];
+    uint8_t device_tree[16];
 } rt_stats;
+#define RT_STATS_MAX_DEVICES 16
 
 /* ---- context: stands where ThreadPool::new() does (main.rs:443) ---------------------- */
 int rt_context_create(int device_id, rt_context** out);
@@ -171,14 +191,20 @@ int rt_scene_begin_group(rt_scene* scene, int kind, int axis);
 int rt_scene_end_group(rt_scene* scene);
 int rt_scene_set_root(rt_scene* scene, int root_kind);
 /* How the trees inside meshes are split (before rt_scene_commit).  REFERENCE: Mesh::build_bvh's
- * stable median split on min[axis] (shape.rs:264-290): the reference's visiting order, hits exact
- * by construction.  SAH is opt-in and has no counterpart in the reference: the same entry format,
- * box padding and one triangle per leaf, but nodes are split where a binned surface-area
- * heuristic is cheapest, which cuts the box tests per ray severalfold on meshes that mix large
- * and small triangles.  The closest hit is the same primitive and the same t unless two
- * primitives tie in t or a box test and a primitive test disagree within rounding (the
- * reference resolves both by its visiting order). */
-enum { RT_BUILD_REFERENCE = 0, RT_BUILD_SAH = 1 };
+ * stable median split on min[axis] (shape.rs:264-290): the reference's trees, and in the PER_LANE
+ * and SWEEP traversals the reference's visiting order, hits exact by construction.  SAH has no
+ * counterpart in the reference: the same entry format, box padding and one triangle per leaf, but
+ * nodes are split where a binned surface-area heuristic is cheapest, which cuts the box tests per
+ * ray severalfold on meshes that mix large and small triangles.  The box and primitive tests are
+ * the reference's and exact ties in t are resolved by primitive key (see rt_scene_get_prim_order),
+ * so the closest hit is the reference's primitive at the reference's t on every ray the tests and
+ * fuzz campaigns of this library have traced; what is not excluded by construction is a box that
+ * rounding closes in front of a primitive whose own test accepts the ray, which another tree's
+ * boxes need not repeat.  AUTO (the default) builds both: the explicit traversal modes run on the
+ * reference's trees, and RT_TRAVERSAL_AUTO may move the scene to the surface-area trees on its
+ * first render (see rt_scene_set_traversal).  A scene without a GPU context builds the
+ * reference's trees only under AUTO. */
+enum { RT_BUILD_REFERENCE = 0, RT_BUILD_SAH = 1, RT_BUILD_AUTO = 2 };
 int rt_scene_set_build(rt_scene* scene, int build_mode);
 /* the build mode of scenes created from now on (process-wide; the scene constructors of
  * rt_host.h create their scenes internally and take it from here) */
@@ -198,34 +224,36 @@ int rt_scene_set_cache_dir(rt_scene* scene, const char* dir);
 int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CACHE_* */
 /* How the closest-hit kernel walks the flattened trees.  PER_LANE and SWEEP visit the same
  * entries in the same order with the same arithmetic as the reference's recursion
- * (shape.rs:142-158, 292-324) and give bit-identical hits; they differ in speed only.
- * PER_LANE: every lane follows its own cursor (any scene size).  SWEEP: the wave sweeps the
- * entry array once with scalar fetches (small scenes).  AUTO picks one of these two: the walk
- * above 192 entries; below, the first render of the scene times both on a small probe batch of
- * its own frame and keeps the faster (a closed room favours the sweep, scattered objects the
- * walk).
- * ORDERED is opt-in and has no counterpart in the reference: the same trees, the same box and
- * primitive tests, but at every box the child nearer along the ray is visited first (per-lane
- * stack), so the narrowed t_max culls far more boxes.  The closest hit is the same primitive and
- * the same t unless two primitives tie in t or a box test and a primitive test disagree within
- * rounding (the reference resolves both by its visiting order); it is therefore not exact by
- * construction.  Fails with RT_ERR_UNSUPPORTED for scenes of 2^29 entries or more, or boxes
- * nested deeper than 64.
- * OCTANT is opt-in too and visits what ORDERED visits, without a stack: the device holds eight
- * copies of the flattened trees, one per sign combination of a ray's direction, each in the
- * pre-order in which that octant's rays meet the nearer child of every box first; a ray walks the
- * copy of its octant with the same skip links as PER_LANE.  Eight times the tree memory (the
- * 10 M-triangle scene: about 6.5 GB of the 288 GB) buys the ordered walk's culling at the plain walk's
- * cost per visit.  Same caveat on ties and same limits as ORDERED; needs a device context.
- * WIDE is opt-in too and walks another tree: on its first use the scene's flattened trees (of either
- * build mode) are collapsed into nodes of up to eight children whose boxes the node stores itself,
- * quantised to 8 bits per plane on a grid of the node (80 bytes per node, always enclosing the true
- * boxes), with every primitive a leaf of its own.  A lane fetches a node, tests its eight boxes at
- * once, and visits the children that were hit nearest first, the rest waiting on a per-lane stack
- * of one word per level.  The primitive tests are the reference's, so t is theirs; the caveat on
- * ties and on box tests within rounding is that of ORDERED.  Fails with RT_ERR_UNSUPPORTED for
- * scenes with transformed meshes, trees deeper than 60 wide levels or of 2^24 node slots and more.
- * May be called before or after rt_scene_commit(). */
+ * (shape.rs:142-158, 292-324) and give bit-identical hits by construction (on the reference's
+ * trees); they differ in speed only.  PER_LANE: every lane follows its own cursor (any scene
+ * size).  SWEEP: the wave sweeps the entry array once with scalar fetches (small scenes).
+ * AUTO takes the fastest form whose hits are the reference's: the first render of the scene times
+ * the candidates on a probe batch of its own frame and keeps the winner (rt_stats.kernel_form and
+ * rt_stats.tree say which).  Candidates: on the reference's trees the sweep (up to 192 entries)
+ * and the per-lane walk (out of LDS when the trees fit, else from memory, plain or with idle lanes
+ * refilled); for a scene of RT_BUILD_AUTO the same forms on the surface-area trees and, when those
+ * do not fit LDS, the wide walk over them.  Every candidate reports the reference's primitive and
+ * t on every ray (ties in t by primitive key), so the frame does not depend on the choice.
+ * ORDERED has no counterpart in the reference: the same trees, the same box and primitive tests,
+ * but at every box the child nearer along the ray is visited first (per-lane stack), so the
+ * narrowed t_max culls far more boxes; ties in t are resolved by primitive key.  Fails with
+ * RT_ERR_UNSUPPORTED for scenes of 2^29 entries or more, or boxes nested deeper than 64.
+ * OCTANT visits what ORDERED visits, without a stack: the device holds eight copies of the
+ * flattened trees, one per sign combination of a ray's direction, each in the pre-order in which
+ * that octant's rays meet the nearer child of every box first; a ray walks the copy of its octant
+ * with the same skip links as PER_LANE.  Eight times the tree memory (the 10 M-triangle scene: about
+ * 6.5 GB of the 288 GB) buys the ordered walk's culling at the plain walk's cost per visit.  Same
+ * limits as ORDERED; needs a device context.
+ * WIDE walks another tree: on its first use the scene's flattened trees are collapsed into nodes of
+ * up to eight children whose boxes the node stores itself, quantised to 8 bits per plane on a grid
+ * of the node (80 bytes per node, always enclosing the true boxes), with every primitive a leaf of
+ * its own.  A lane fetches a node, tests its eight boxes at once, and visits the children that were
+ * hit nearest first, the rest waiting on a per-lane stack of one word per level.  The primitive
+ * tests are the reference's, so t is theirs, and ties go by primitive key.  Fails with
+ * RT_ERR_UNSUPPORTED for scenes with transformed meshes, trees deeper than 60 wide levels or of
+ * 2^24 node slots and more.
+ * The explicit modes run on the reference's trees (on the surface-area trees for a scene built with
+ * RT_BUILD_SAH).  May be called before or after rt_scene_commit(). */
 enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2, RT_TRAVERSAL_ORDERED = 3,
        RT_TRAVERSAL_OCTANT = 4, RT_TRAVERSAL_WIDE = 5 };
 int rt_scene_set_traversal(rt_scene* scene, int mode);
@@ -240,7 +268,8 @@ int rt_scene_set_traversal(rt_scene* scene, int mode);
  * the objects of a list at the root are not marked (see rt_scene_wide_info). */
 enum { RT_WIDE_BUILD_COLLAPSE = 0, RT_WIDE_BUILD_DEVICE = 1 };
 int rt_scene_set_wide_build(rt_scene* scene, int where);
-/* builds the reference-topology BVHs (shape.rs:94-138, 264-290), flattens them and uploads */
+/* builds the trees of the scene's build mode (the reference topology: shape.rs:94-138, 264-290),
+ * flattens them and uploads */
 int rt_scene_commit(rt_scene* scene);
 size_t rt_scene_num_prims(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
@@ -354,6 +383,17 @@ int rt_render_multi(rt_scene* scene, const rt_camera* cam, const rt_render_param
 /* same, adding into a buffer on GPU 0 (the root) of the context */
 int rt_render_multi_device(rt_scene* scene, const rt_camera* cam, const rt_render_params* params,
                            void* d_accum_rgb, rt_stats* stats);
+/* How rt_render_multi combines the GPUs' frames (no counterpart in the reference, whose workers write
+ * disjoint tiles of one buffer, main.rs:397-405).  RCCL (default): one ncclReduce(sum, f32, root 0);
+ * the order in which RCCL adds the partial sums of a pixel is its own, fixed for a given node
+ * topology and GPU count.  ORDERED: every peer's frame is copied to the root (hipMemcpyPeerAsync
+ * over xGMI) and added there by a kernel in rank order, so the sum of a pixel is
+ * ((f0 + f1) + f2) + ... whatever the topology: the strict-order form for callers who need frames
+ * that are bit-identical across machines.  A context whose dev_ids name one GPU several times always
+ * adds in rank order.  The environment variable RT_REDUCE_ORDERED=1 makes ORDERED the default of
+ * contexts created afterwards. */
+enum { RT_REDUCE_RCCL = 0, RT_REDUCE_ORDERED = 1 };
+int rt_context_set_reduce(rt_context* ctx, int mode);
 
 /* ---- tonemap: main.rs:369-373 + rgb_to_u32 (math.rs:112-116) --------------------------- */
 int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out_0rgb, size_t npix);

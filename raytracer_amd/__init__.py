@@ -28,7 +28,9 @@ MAT_LAMBERT, MAT_METAL, MAT_DIELECTRIC, MAT_EMISSIVE = 0, 1, 2, 3
 MAT_FLAG_NORMAL_SHADING = 1
 ROOT_BVH, ROOT_SINGLE, ROOT_LIST = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_SWEEP, TRAVERSAL_ORDERED, TRAVERSAL_OCTANT, TRAVERSAL_WIDE = 0, 1, 2, 3, 4, 5
-BUILD_REFERENCE, BUILD_SAH = 0, 1
+BUILD_REFERENCE, BUILD_SAH, BUILD_AUTO = 0, 1, 2
+TREE_NAMES = ("reference", "sah")
+REDUCE_RCCL, REDUCE_ORDERED = 0, 1
 WIDE_BUILD_COLLAPSE, WIDE_BUILD_DEVICE = 0, 1
 CACHE_OFF, CACHE_STORED, CACHE_LOADED, CACHE_STORE_FAILED = 0, 1, 2, 3
 MISS = 0xFFFFFFFF
@@ -62,10 +64,14 @@ class Stats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("paths", C.c_uint64), ("box_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("sph_tests", C.c_uint64), ("trace_launches", C.c_uint64),
                 ("ms_render", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
-                ("ms_reduce", C.c_double), ("n_devices", C.c_uint32), ("kernel_form", C.c_uint32)]
+                ("ms_reduce", C.c_double), ("n_devices", C.c_uint32), ("kernel_form", C.c_uint32),
+                ("tree", C.c_uint32), ("rccl_ranks", C.c_uint32), ("ms_kernel_span", C.c_double),
+                ("ms_render_min", C.c_double), ("slowest_device", C.c_uint32), ("reduce_mode", C.c_uint32),
+                ("shader_clock_ghz", C.c_double), ("device_ms_render", C.c_float * 16),
+                ("device_form", C.c_uint8 * 16), ("device_tree", C.c_uint8 * 16)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("device_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class RtError(RuntimeError):
@@ -89,6 +95,7 @@ def _load():
         "rt_context_create": (i32, [i32, pp]),
         "rt_context_create_multi": (i32, [i32, C.POINTER(i32), pp]),
         "rt_context_num_devices": (i32, [vp]),
+        "rt_context_set_reduce": (i32, [vp, i32]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, []),
         "rt_context_stream": (vp, [vp]),
@@ -162,7 +169,7 @@ def _load():
 
 lib = _load()
 ABI_SYMBOLS = [
-    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_destroy", "rt_last_error",
+    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_set_reduce", "rt_context_destroy", "rt_last_error",
     "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
@@ -228,6 +235,10 @@ class Context:
     @property
     def num_devices(self):
         return lib.rt_context_num_devices(self.h)
+
+    def set_reduce(self, mode):
+        """REDUCE_RCCL (one ncclReduce) or REDUCE_ORDERED (peer frames copied to the root, added in rank order)."""
+        _check(lib.rt_context_set_reduce(self.h, mode))
 
     def close(self):
         if getattr(self, "h", None):

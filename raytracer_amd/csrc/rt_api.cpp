@@ -14,6 +14,8 @@
 #include <mutex>
 #include <new>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -25,7 +27,7 @@ using namespace rtamd;
 namespace {
 
 thread_local std::string g_last_error;
-std::atomic<int> g_default_build{RT_BUILD_REFERENCE};   // rt_set_default_build
+std::atomic<int> g_default_build{RT_BUILD_AUTO};        // rt_set_default_build
 std::mutex g_cache_dir_lock;
 std::string g_default_cache_dir;                        // rt_set_default_cache_dir
 
@@ -90,6 +92,44 @@ struct Pipe {
 
 constexpr int MAX_PIPES = 4;
 
+// A host thread that lives as long as its multi-GPU context and drives one peer GPU: rt_render_multi
+// hands it one job per call instead of starting a thread per GPU and call.  Jobs must not throw.
+struct HostWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, quit = false;
+    std::thread th;
+    HostWorker() : th([this]() { loop(); }) {}
+    ~HostWorker() {
+        { std::lock_guard<std::mutex> g(m); quit = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void loop() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&]() { return has_job || quit; });
+            if (quit) return;
+            std::function<void()> j = std::move(job);
+            has_job = false;
+            lk.unlock();
+            j();
+            lk.lock();
+            done = true;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<void()> j) {
+        { std::lock_guard<std::mutex> g(m); job = std::move(j); has_job = true; done = false; }
+        cv.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&]() { return done; });
+    }
+};
+
 struct rt_context {
     int device = 0;
     hipStream_t stream = nullptr;       // = pipes[0].stream: the stream callers may order work on
@@ -97,6 +137,7 @@ struct rt_context {
     Pipe pipes[MAX_PIPES];
     DeviceBuffer totals, scratch_in, scratch_out;
     DeviceBuffer trace_partials;        // rt_trace_device with counts: one record per workgroup
+    DeviceBuffer clock_stamps;          // profiled renders: four words per launch of the per-batch kernel
     DeviceBuffer frame_in, frame_out;   // rt_render / rt_tonemap: device copies of the caller's host buffers
     void* static_scratch = nullptr;     // this device's copy of the library's static array (rt_trace_device_static)
     uint32_t wave_target = 8192, wave_target_sweep = 8192;
@@ -112,7 +153,10 @@ struct rt_context {
     std::vector<rt_context*> peers;     // GPUs 1 .. n-1 (owned)
     std::vector<ncclComm_t> comms;      // one communicator per GPU, [0] the root's; empty when the GPUs are not distinct
     bool multi = false;                 // made by rt_context_create_multi (even with one GPU)
-    DeviceBuffer frame;                 // a peer's full-frame accumulation buffer (rt_render_multi)
+    DeviceBuffer frame;                 // this GPU's full-frame accumulation buffer of a rt_render_multi call
+    DeviceBuffer stage;                 // root: where a peer's frame lands before it is added (ordered reduce)
+    int reduce_mode = RT_REDUCE_RCCL;   // rt_context_set_reduce
+    std::vector<std::unique_ptr<HostWorker>> workers;   // root: one host thread per peer GPU
 
     LaunchCfg cfg(int pipe = 0) const { return LaunchCfg{(void*)pipes[pipe].stream, grid_cap, wave_target}; }
     ~rt_context() {
@@ -128,6 +172,20 @@ struct rt_context {
     }
 };
 
+// One flattened form of a scene's trees on one GPU: the reference-topology trees, or the
+// surface-area trees of RT_BUILD_SAH / RT_BUILD_AUTO.  The per-primitive tables are the scene's.
+struct SceneTree {
+    bool present = false;
+    uint32_t n_entries = 0, n_units = 0, n_walk = 0, walk_top_units = 0, depth = 0;
+    bool ordered_ok = false;
+    bool multi_child = false;           // a box with more than two children: no ordered walk (the octant walk is fine)
+    bool lds_walk = false;              // the linked units fit the LDS of a workgroup
+    DeviceBuffer d_entries, d_units, d_walk, d_units_oct;
+    DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
+    WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
+};
+enum { TREE_REFERENCE = 0, TREE_FAST = 1 };
+
 struct rt_scene {
     rt_context* ctx = nullptr;
     std::vector<rt_material> mats;
@@ -135,23 +193,26 @@ struct rt_scene {
     std::vector<SceneGroup> groups{SceneGroup{}};      // [0]: the top level
     std::vector<size_t> open_groups{0};                // rt_scene_begin_group nesting
     int root_kind = RT_ROOT_BVH;
-    int build_mode = RT_BUILD_REFERENCE;
+    int build_mode = RT_BUILD_AUTO;
     int traversal = RT_TRAVERSAL_AUTO;
-    bool ordered_ok = false;
-    bool multi_child = false;           // a box with more than two children: no ordered walk (the octant walk is fine)
     bool auto_tuned = false;            // the first render has timed the forms of the closest-hit loop that apply
     uint32_t env_prim_wait = 0;         // RT_PRIM_WAIT, 0 when unset
     uint32_t env_refill = 0;            // RT_REFILL, 0 when unset
     bool committed = false;
     std::string cache_dir;              // rt_scene_set_cache_dir; empty: the scene is always built
     int cache_state = RT_CACHE_OFF;
-    FlatScene flat;
-    DeviceBuffer d_entries, d_units, d_walk, d_units_oct, d_geo, d_meta, d_order, d_mats, d_xforms;
-    DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
-    WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
+    FlatScene flat;                     // the tree host-only scenes show: the reference's (RT_BUILD_SAH: the surface-area one)
+    SceneTree trees[2];                 // [TREE_REFERENCE], [TREE_FAST]; which exist follows from the build mode
+    int cur = TREE_REFERENCE;           // the tree `dev` is bound to
+    DeviceBuffer d_geo, d_meta, d_order, d_mats, d_xforms;
     int wide_build = RT_WIDE_BUILD_COLLAPSE;            // where the wide tree is made: rt_scene_set_wide_build
     DevScene dev{};
     std::vector<rt_scene*> replicas;    // the committed scene on GPUs 1 .. n-1 of a multi-GPU context (owned)
+
+    SceneTree& tree() { return trees[cur]; }
+    const SceneTree& tree() const { return trees[cur]; }
+    // the tree explicit traversal modes run on: the reference's wherever the scene has it
+    int base_tree() const { return trees[TREE_REFERENCE].present ? TREE_REFERENCE : TREE_FAST; }
 };
 
 #ifdef RT_STAMPS
@@ -270,11 +331,19 @@ int rt_context_create_multi(int n_dev, const int* dev_ids, rt_context** out) {
     int rc = rt_context_create(dev_ids[0], &root);
     if (rc) return rc;
     root->multi = true;
+    if (const char* e = std::getenv("RT_REDUCE_ORDERED"))
+        if (std::atoi(e) != 0) root->reduce_mode = RT_REDUCE_ORDERED;
     for (int i = 1; i < n_dev; i++) {
         rt_context* peer = nullptr;
         rc = rt_context_create(dev_ids[i], &peer);
         if (rc) { rt_context_destroy(root); return rc; }
         root->peers.push_back(peer);
+    }
+    try {
+        for (int i = 1; i < n_dev; i++) root->workers.emplace_back(new HostWorker());
+    } catch (...) {
+        rt_context_destroy(root);
+        throw;
     }
     if (distinct) {                            // one RCCL rank per GPU, all driven by this process
         root->comms.assign((size_t)n_dev, nullptr);
@@ -292,9 +361,18 @@ int rt_context_create_multi(int n_dev, const int* dev_ids, rt_context** out) {
 
 int rt_context_num_devices(const rt_context* ctx) { return ctx ? 1 + (int)ctx->peers.size() : 0; }
 
+int rt_context_set_reduce(rt_context* ctx, int mode) {
+    if (!ctx) return fail(RT_ERR_INVALID, "rt_context_set_reduce: NULL context");
+    if (mode != RT_REDUCE_RCCL && mode != RT_REDUCE_ORDERED) return fail(RT_ERR_INVALID, "rt_context_set_reduce: unknown mode");
+    if (!ctx->multi) return fail(RT_ERR_STATE, "rt_context_set_reduce needs a context made by rt_context_create_multi");
+    ctx->reduce_mode = mode;
+    return RT_OK;
+}
+
 void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     if (ctx->destroyed) return;
+    ctx->workers.clear();                      // joins the peers' host threads
     for (ncclComm_t c : ctx->comms)
         if (c) (void)ncclCommDestroy(c);
     ctx->comms.clear();
@@ -428,86 +506,125 @@ int rt_scene_set_root(rt_scene* s, int root_kind) {
     return RT_OK;
 }
 
-// the kernel form a committed scene is traced with
+// binds the per-tree fields of s->dev to one of the scene's trees
+static void bind_tree(rt_scene* s, int which) {
+    const SceneTree& t = s->trees[which];
+    s->cur = which;
+    s->dev.entries = t.d_entries.p;
+    s->dev.units = t.d_units.p;
+    s->dev.walk = t.d_walk.p;
+    s->dev.units_oct = t.d_units_oct.p;
+    s->dev.n_entries = t.n_entries;
+    s->dev.n_units = t.n_units;
+    s->dev.n_walk = t.n_walk;
+    s->dev.walk_top_units = t.walk_top_units;
+    s->dev.stack_depth = std::max<uint32_t>(t.depth, 1u);
+    s->dev.lds_walk = t.lds_walk ? 1u : 0u;
+    s->dev.wide_nodes = t.d_wide_nodes.p;
+    s->dev.wide_prims = t.d_wide_prims.p;
+    s->dev.wide_stack = std::max(1u, t.wide.depth);
+    s->dev.wide_stride = t.wide.node_words / 4u;
+}
+
+// the eight direction-ordered copies of the bound tree's units (octant walk), made on first use
+static int ensure_octant_units(rt_scene* s) {
+    SceneTree& t = s->tree();
+    if (!t.ordered_ok)
+        return fail(RT_ERR_UNSUPPORTED, "octant traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
+    if (((uint64_t)t.n_units + UNITS_END) * 8u > SKIP_MASK)
+        return fail(RT_ERR_UNSUPPORTED, "octant traversal: eight copies of the trees exceed the 30-bit links");
+    if (!s->ctx) return fail(RT_ERR_DEVICE, "octant traversal needs a device context");
+    if (!t.d_units_oct.p) {
+        int rc = set_device(s->ctx);
+        if (rc) return rc;
+        std::vector<uint32_t> units((size_t)t.n_units * 4), oct;
+        HIP_TRY(hipMemcpy(units.data(), t.d_units.p, units.size() * 4, hipMemcpyDeviceToHost));
+        build_octant_units(units.data(), t.n_units, oct);
+        HIP_TRY(t.d_units_oct.ensure(oct.size() * 4));
+        HIP_TRY(hipMemcpy(t.d_units_oct.p, oct.data(), oct.size() * 4, hipMemcpyHostToDevice));
+    }
+    return RT_OK;
+}
+
+// the wide tree of the bound tree, made on first use: built on this GPU from the primitives, or
+// collapsed on the host from the entry array (once for all GPUs of a context)
+static int ensure_wide_tree(rt_scene* s) {
+    SceneTree& t = s->tree();
+    const int which = s->cur;
+    if (!t.d_wide_nodes.p && s->wide_build == RT_WIDE_BUILD_DEVICE) {
+        int rc = set_device(s->ctx);
+        if (rc) return rc;
+        WideDeviceTree w;
+        std::string err;
+        const auto t_begin = std::chrono::steady_clock::now();
+        if (build_wide_on_device((void*)s->ctx->stream, t.d_entries.p, t.n_entries, w, err))
+            return fail(RT_ERR_DEVICE, "wide traversal, device build: " + err);
+        if (std::getenv("RT_BUILD_TIMING"))
+            std::fprintf(stderr, "[rt build] wide tree on the GPU         %.3f s (%u node slots, %u primitives, %u levels)\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), w.n_slots,
+                         w.n_prims, w.depth);
+        t.d_wide_nodes.release(); t.d_wide_nodes.p = w.nodes; t.d_wide_nodes.bytes = w.nodes_bytes;
+        t.d_wide_prims.release(); t.d_wide_prims.p = w.prims; t.d_wide_prims.bytes = w.prims_bytes;
+        t.wide.depth = w.depth;
+        t.wide.node_words = w.node_words;
+    }
+    if (!t.d_wide_nodes.p) {
+        int rc = set_device(s->ctx);
+        if (rc) return rc;
+        std::vector<float> entries((size_t)t.n_entries * ENTRY_FLOATS);
+        HIP_TRY(hipMemcpy(entries.data(), t.d_entries.p, entries.size() * 4, hipMemcpyDeviceToHost));
+        WideScene w;
+        const auto t_begin = std::chrono::steady_clock::now();
+        const std::string err = build_wide_scene(entries.data(), t.n_entries, w);
+        if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
+        if (std::getenv("RT_BUILD_TIMING"))
+            std::fprintf(stderr, "[rt build] wide tree                    %.3f s (%zu node slots, %zu primitives, %u levels)\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), w.n_nodes(),
+                         w.n_prims(), w.depth);
+        entries.clear(); entries.shrink_to_fit();
+        // the tree is built once: the scene's copies on the other GPUs of a multi-GPU context get the same arrays
+        std::vector<rt_scene*> targets{s};
+        for (rt_scene* r : s->replicas)
+            if (!r->trees[which].d_wide_nodes.p) targets.push_back(r);
+        for (rt_scene* g : targets) {
+            SceneTree& gt = g->trees[which];
+            rc = set_device(g->ctx);
+            if (rc) return rc;
+            gt.wide.depth = w.depth;
+            gt.wide.node_words = w.node_words;
+            HIP_TRY(gt.d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
+            HIP_TRY(hipMemcpy(gt.d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(gt.d_wide_nodes.ensure(w.nodes.size() * 4));
+            HIP_TRY(hipMemcpy(gt.d_wide_nodes.p, w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
+        }
+        rc = set_device(s->ctx);
+        if (rc) return rc;
+    }
+    return RT_OK;
+}
+
+// the kernel form a committed scene is traced with.  An explicit mode runs on the scene's base tree
+// (the reference's trees unless the scene was built with RT_BUILD_SAH alone); AUTO starts there too,
+// and the first render may move a scene of RT_BUILD_AUTO to its other tree.
 static int apply_traversal(rt_scene* s, int mode) {
+    bind_tree(s, s->base_tree());
+    const SceneTree& t = s->tree();
     if (s->dev.n_xforms != 0 && mode != RT_TRAVERSAL_AUTO && mode != RT_TRAVERSAL_PER_LANE)
         return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
-    if (mode == RT_TRAVERSAL_ORDERED && s->multi_child)
+    if (mode == RT_TRAVERSAL_ORDERED && t.multi_child)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal takes boxes of at most two children (no leaves of several triangles, "
                                         "no list inside a Bvh); the octant traversal visits the same entries without that limit");
-    if (mode == RT_TRAVERSAL_ORDERED && !s->ordered_ok)
+    if (mode == RT_TRAVERSAL_ORDERED && !t.ordered_ok)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
     if (mode == RT_TRAVERSAL_OCTANT) {
-        if (!s->ordered_ok)
-            return fail(RT_ERR_UNSUPPORTED, "octant traversal needs fewer than 2^29 entries and boxes nested at most 64 deep");
-        if (((uint64_t)s->dev.n_units + UNITS_END) * 8u > SKIP_MASK)
-            return fail(RT_ERR_UNSUPPORTED, "octant traversal: eight copies of the trees exceed the 30-bit links");
-        if (!s->ctx) return fail(RT_ERR_DEVICE, "octant traversal needs a device context");
-        if (!s->d_units_oct.p) {   // first use: the eight copies, from the device's unit array
-            int rc = set_device(s->ctx);
-            if (rc) return rc;
-            std::vector<uint32_t> units((size_t)s->dev.n_units * 4), oct;
-            HIP_TRY(hipMemcpy(units.data(), s->d_units.p, units.size() * 4, hipMemcpyDeviceToHost));
-            build_octant_units(units.data(), s->dev.n_units, oct);
-            HIP_TRY(s->d_units_oct.ensure(oct.size() * 4));
-            HIP_TRY(hipMemcpy(s->d_units_oct.p, oct.data(), oct.size() * 4, hipMemcpyHostToDevice));
-        }
-        s->dev.units_oct = s->d_units_oct.p;
+        int rc = ensure_octant_units(s);
+        if (rc) return rc;
     }
     if (mode == RT_TRAVERSAL_WIDE && s->ctx) {
-        if (!s->d_wide_nodes.p && s->wide_build == RT_WIDE_BUILD_DEVICE) {     // first use: built on this GPU
-            int rc = set_device(s->ctx);
-            if (rc) return rc;
-            WideDeviceTree t;
-            std::string err;
-            const auto t_begin = std::chrono::steady_clock::now();
-            if (build_wide_on_device((void*)s->ctx->stream, s->d_entries.p, s->dev.n_entries, t, err))
-                return fail(RT_ERR_DEVICE, "wide traversal, device build: " + err);
-            if (std::getenv("RT_BUILD_TIMING"))
-                std::fprintf(stderr, "[rt build] wide tree on the GPU         %.3f s (%u node slots, %u primitives, %u levels)\n",
-                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), t.n_slots,
-                             t.n_prims, t.depth);
-            s->d_wide_nodes.release(); s->d_wide_nodes.p = t.nodes; s->d_wide_nodes.bytes = t.nodes_bytes;
-            s->d_wide_prims.release(); s->d_wide_prims.p = t.prims; s->d_wide_prims.bytes = t.prims_bytes;
-            s->wide.depth = t.depth;
-            s->wide.node_words = t.node_words;
-        }
-        if (!s->d_wide_nodes.p) {  // first use: the wide tree, collapsed from the device's entry array
-            int rc = set_device(s->ctx);
-            if (rc) return rc;
-            std::vector<float> entries((size_t)s->dev.n_entries * ENTRY_FLOATS);
-            HIP_TRY(hipMemcpy(entries.data(), s->d_entries.p, entries.size() * 4, hipMemcpyDeviceToHost));
-            WideScene w;
-            const auto t_begin = std::chrono::steady_clock::now();
-            const std::string err = build_wide_scene(entries.data(), s->dev.n_entries, w);
-            if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
-            if (std::getenv("RT_BUILD_TIMING"))
-                std::fprintf(stderr, "[rt build] wide tree                    %.3f s (%zu node slots, %zu primitives, %u levels)\n",
-                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), w.n_nodes(),
-                             w.n_prims(), w.depth);
-            entries.clear(); entries.shrink_to_fit();
-            // the tree is built once: the scene's copies on the other GPUs of a multi-GPU context get the same arrays
-            std::vector<rt_scene*> targets{s};
-            for (rt_scene* r : s->replicas)
-                if (!r->d_wide_nodes.p) targets.push_back(r);
-            for (rt_scene* t : targets) {
-                rc = set_device(t->ctx);
-                if (rc) return rc;
-                t->wide.depth = w.depth;
-                t->wide.node_words = w.node_words;
-                HIP_TRY(t->d_wide_prims.ensure(std::max<size_t>(w.prims.size() * 4, 64)));
-                HIP_TRY(hipMemcpy(t->d_wide_prims.p, w.prims.data(), w.prims.size() * 4, hipMemcpyHostToDevice));
-                HIP_TRY(t->d_wide_nodes.ensure(w.nodes.size() * 4));
-                HIP_TRY(hipMemcpy(t->d_wide_nodes.p, w.nodes.data(), w.nodes.size() * 4, hipMemcpyHostToDevice));
-            }
-            rc = set_device(s->ctx);
-            if (rc) return rc;
-        }
-        s->dev.wide_nodes = s->d_wide_nodes.p;
-        s->dev.wide_prims = s->d_wide_prims.p;
-        s->dev.wide_stack = std::max(1u, s->wide.depth);
-        s->dev.wide_stride = s->wide.node_words / 4u;
+        int rc = ensure_wide_tree(s);
+        if (rc) return rc;
     }
+    bind_tree(s, s->cur);                      // (the arrays made above)
     {   // experiment knobs, read whenever the kernel form is (re)chosen.  RT_PRIM_WAIT: lanes that must
         // wait at primitives before their routine runs (best of {1 .. 64} measured on the sphere and OBJ
         // scenes, from memory and out of LDS alike: 8; 2 .. 12 lie within 3 %).  RT_REFILL: idle lanes
@@ -522,7 +639,7 @@ static int apply_traversal(rt_scene* s, int mode) {
     s->dev.wide = mode == RT_TRAVERSAL_WIDE && s->ctx ? 1u : 0u;
     // out of the reference's visiting order (another tree, or nearer child first) exact ties in t are
     // resolved by primitive key
-    s->dev.tie = (s->build_mode != RT_BUILD_REFERENCE || s->dev.octant || s->dev.ordered || s->dev.wide) ? 1u : 0u;
+    s->dev.tie = (s->cur != TREE_REFERENCE || s->dev.octant || s->dev.ordered || s->dev.wide) ? 1u : 0u;
     s->auto_tuned = false;
     s->dev.refill = s->env_refill;
     s->dev.prim_wait = s->env_prim_wait ? s->env_prim_wait : 8u;
@@ -552,8 +669,10 @@ static int apply_traversal(rt_scene* s, int mode) {
     return RT_OK;
 }
 
+static bool known_build(int m) { return m == RT_BUILD_REFERENCE || m == RT_BUILD_SAH || m == RT_BUILD_AUTO; }
+
 int rt_set_default_build(int build_mode) {
-    if (build_mode != RT_BUILD_REFERENCE && build_mode != RT_BUILD_SAH) return fail(RT_ERR_INVALID, "unknown build mode");
+    if (!known_build(build_mode)) return fail(RT_ERR_INVALID, "unknown build mode");
     g_default_build.store(build_mode);
     return RT_OK;
 }
@@ -561,7 +680,7 @@ int rt_set_default_build(int build_mode) {
 int rt_scene_set_build(rt_scene* s, int build_mode) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_build: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
-    if (build_mode != RT_BUILD_REFERENCE && build_mode != RT_BUILD_SAH) return fail(RT_ERR_INVALID, "unknown build mode");
+    if (!known_build(build_mode)) return fail(RT_ERR_INVALID, "unknown build mode");
     s->build_mode = build_mode;
     return RT_OK;
 }
@@ -588,7 +707,8 @@ int rt_scene_cache_state(const rt_scene* s) { return s ? s->cache_state : RT_CAC
 int rt_scene_set_wide_build(rt_scene* s, int where) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_set_wide_build: NULL scene");
     if (where != RT_WIDE_BUILD_COLLAPSE && where != RT_WIDE_BUILD_DEVICE) return fail(RT_ERR_INVALID, "unknown wide build");
-    if (s->d_wide_nodes.p) return fail(RT_ERR_STATE, "rt_scene_set_wide_build: the scene's wide tree has been made already");
+    if (s->trees[0].d_wide_nodes.p || s->trees[1].d_wide_nodes.p)
+        return fail(RT_ERR_STATE, "rt_scene_set_wide_build: the scene's wide tree has been made already");
     s->wide_build = where;
     for (rt_scene* r : s->replicas) {
         int rc = rt_scene_set_wide_build(r, where);
@@ -614,17 +734,24 @@ int rt_scene_set_traversal(rt_scene* s, int mode) {
     RT_GUARD_END("rt_scene_set_traversal")
 }
 
-// uploads a flattened scene to the GPU of s->ctx and chooses the kernel form
-static int upload_scene(rt_scene* s, const FlatScene& f) {
+// what a tree's SceneTree records of its flattened form (host-only scenes stop here)
+static void describe_tree(SceneTree& t, const FlatScene& f) {
+    t.present = true;
+    t.n_entries = (uint32_t)f.n_entries();
+    t.n_units = (uint32_t)f.n_units();
+    t.n_walk = (uint32_t)f.n_walk();
+    t.walk_top_units = f.walk_top_units;
+    t.depth = f.depth;
+    t.ordered_ok = f.ordered_ok;
+    t.multi_child = f.multi_child;
+    t.lds_walk = t.n_walk > 0 && ((size_t)t.n_walk + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES && !std::getenv("RT_NO_LDS_WALK");
+}
+
+// uploads one flattened tree to the GPU of s->ctx
+static int upload_tree(rt_scene* s, int which, const FlatScene& f) {
     rt_context* ctx = s->ctx;
-    s->dev.n_entries = (uint32_t)f.n_entries();
-    s->dev.n_prims = (uint32_t)f.n_prims();
-    s->ordered_ok = f.ordered_ok;
-    s->multi_child = f.multi_child;
-    s->dev.n_units = (uint32_t)f.n_units();
-    s->dev.n_walk = (uint32_t)f.n_walk();
-    s->dev.walk_top_units = f.walk_top_units;
-    s->dev.stack_depth = std::max<uint32_t>(f.depth, 1u);
+    SceneTree& t = s->trees[which];
+    describe_tree(t, f);
     int rc = set_device(ctx);
     if (rc) return rc;
     auto upload = [&](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
@@ -636,23 +763,35 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
         float end_entry[ENTRY_FLOATS] = {};
         const uint32_t w = TAG_END << TAG_SHIFT;
         std::memcpy(&end_entry[3], &w, 4);
-        HIP_TRY(s->d_entries.ensure(f.entries.size() * 4 + sizeof(end_entry)));
-        HIP_TRY(hipMemcpyAsync((char*)s->d_entries.p + f.entries.size() * 4, end_entry, sizeof(end_entry),
+        HIP_TRY(t.d_entries.ensure(f.entries.size() * 4 + sizeof(end_entry)));
+        HIP_TRY(hipMemcpyAsync((char*)t.d_entries.p + f.entries.size() * 4, end_entry, sizeof(end_entry),
                                hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));    // end_entry leaves scope
     }
-    HIP_TRY(upload(s->d_entries, f.entries.data(), f.entries.size() * 4));
-    HIP_TRY(upload(s->d_units, f.units.data(), f.units.size() * 4));
-    HIP_TRY(upload(s->d_walk, f.walk.data(), f.walk.size() * 4));
+    HIP_TRY(upload(t.d_entries, f.entries.data(), f.entries.size() * 4));
+    HIP_TRY(upload(t.d_units, f.units.data(), f.units.size() * 4));
+    HIP_TRY(upload(t.d_walk, f.walk.data(), f.walk.size() * 4));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+// uploads the per-primitive tables (the same for every tree of the scene) and chooses the kernel form
+static int upload_tables(rt_scene* s, const FlatScene& f) {
+    rt_context* ctx = s->ctx;
+    int rc = set_device(ctx);
+    if (rc) return rc;
+    auto upload = [&](DeviceBuffer& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(std::max<size_t>(bytes, 16));
+        if (e != hipSuccess || bytes == 0) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    };
     HIP_TRY(upload(s->d_geo, f.prim_geo.data(), f.prim_geo.size() * 4));
     HIP_TRY(upload(s->d_meta, f.prim_meta.data(), f.prim_meta.size() * 4));
     HIP_TRY(upload(s->d_order, f.prim_order.data(), f.prim_order.size() * 4));
     HIP_TRY(upload(s->d_mats, f.materials.data(), f.materials.size() * 4));
     HIP_TRY(upload(s->d_xforms, f.xforms.data(), f.xforms.size() * 4));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    s->dev.entries = s->d_entries.p;
-    s->dev.units = s->d_units.p;
-    s->dev.walk = s->d_walk.p;
+    s->dev.n_prims = (uint32_t)f.n_prims();
     s->dev.prim_geo = s->d_geo.p;
     s->dev.prim_meta = (const uint32_t*)s->d_meta.p;
     s->dev.prim_order = (const uint32_t*)s->d_order.p;
@@ -662,8 +801,6 @@ static int upload_scene(rt_scene* s, const FlatScene& f) {
     s->dev.n_mats = (uint32_t)(f.materials.size() / 8);
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
-    s->dev.lds_walk = (s->dev.n_walk > 0 && ((size_t)s->dev.n_walk + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES &&
-                       !std::getenv("RT_NO_LDS_WALK")) ? 1u : 0u;
     return apply_traversal(s, s->traversal);
 }
 
@@ -672,40 +809,64 @@ int rt_scene_commit(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_commit: NULL scene");
     if (s->committed) return fail(RT_ERR_STATE, "scene already committed");
     if (s->open_groups.size() != 1) return fail(RT_ERR_STATE, "rt_scene_commit: a container opened with rt_scene_begin_group is not closed");
+    // Which trees the scene gets: the reference's (REFERENCE, AUTO) and / or the surface-area ones (SAH,
+    // AUTO).  A scene without a GPU shows one tree to its inspectors and builds no second one.
+    // (Only the trees inside meshes differ between the two; a mesh of up to two triangles has one shape.)
+    bool splits_differ = false;
+    for (const SceneObject& o : s->objects) splits_differ = splits_differ || (o.is_mesh && o.tris.size() > 2);
+    const bool want_ref = s->build_mode != RT_BUILD_SAH;
+    const bool want_fast = s->build_mode == RT_BUILD_SAH || (s->build_mode == RT_BUILD_AUTO && s->ctx != nullptr && splits_differ);
     // with a cache directory: the flattened arrays come from the file of this description's key when
-    // there is one (and it is complete); otherwise they are built and the file is written for next time
-    std::string cache_path;
-    uint64_t cache_key = 0;
-    bool loaded = false;
+    // there is one (and it is complete and sane); otherwise they are built and the file is written for next time
     s->cache_state = RT_CACHE_OFF;
-    if (!s->cache_dir.empty()) {
-        cache_key = scene_cache_key(s->mats, s->objects, s->groups, s->root_kind, s->build_mode);
-        char name[40];
-        std::snprintf(name, sizeof(name), "/%016llx.rtscene", (unsigned long long)cache_key);
-        cache_path = s->cache_dir + name;
-        loaded = scene_cache_load(cache_path, cache_key, s->flat);
-        if (loaded) s->cache_state = RT_CACHE_LOADED;
-    }
-    if (!loaded) {
-        std::string err = build_flat_scene(s->mats, s->objects, s->groups, s->root_kind, s->build_mode, s->flat);
+    auto flatten = [&](int mode, FlatScene& out, const FlatScene* reference) -> int {
+        std::string cache_path;
+        uint64_t cache_key = 0;
+        if (!s->cache_dir.empty()) {
+            cache_key = scene_cache_key(s->mats, s->objects, s->groups, s->root_kind, mode);
+            char name[40];
+            std::snprintf(name, sizeof(name), "/%016llx.rtscene", (unsigned long long)cache_key);
+            cache_path = s->cache_dir + name;
+            if (scene_cache_load(cache_path, cache_key, out)) {
+                if (s->cache_state == RT_CACHE_OFF) s->cache_state = RT_CACHE_LOADED;
+                return RT_OK;
+            }
+        }
+        std::string err = build_flat_scene(s->mats, s->objects, s->groups, s->root_kind, mode, out, reference);
         if (!err.empty()) return fail(RT_ERR_INVALID, "rt_scene_commit: " + err);
-        if (!cache_path.empty())
-            s->cache_state = scene_cache_store(cache_path, cache_key, s->flat) ? RT_CACHE_STORED : RT_CACHE_STORE_FAILED;
+        if (!cache_path.empty()) {
+            const bool stored = scene_cache_store(cache_path, cache_key, out);
+            if (!stored) s->cache_state = RT_CACHE_STORE_FAILED;
+            else if (s->cache_state != RT_CACHE_STORE_FAILED) s->cache_state = RT_CACHE_STORED;
+        }
+        return RT_OK;
+    };
+    FlatScene fast;
+    if (want_ref) {
+        int rc = flatten(RT_BUILD_REFERENCE, s->flat, nullptr);
+        if (rc) return rc;
     }
+    if (want_fast) {
+        int rc = flatten(RT_BUILD_SAH, want_ref ? fast : s->flat, want_ref ? &s->flat : nullptr);
+        if (rc) return rc;
+    }
+    const FlatScene& f_ref = s->flat;
+    const FlatScene& f_fast = want_ref ? fast : s->flat;
     rt_context* ctx = s->ctx;
-    s->dev.n_entries = (uint32_t)s->flat.n_entries();
+    if (want_ref) describe_tree(s->trees[TREE_REFERENCE], f_ref);
+    if (want_fast) describe_tree(s->trees[TREE_FAST], f_fast);
     s->dev.n_prims = (uint32_t)s->flat.n_prims();
-    s->ordered_ok = s->flat.ordered_ok;
-    s->multi_child = s->flat.multi_child;
-    s->dev.n_units = (uint32_t)s->flat.n_units();
-    s->dev.n_walk = (uint32_t)s->flat.n_walk();
-    s->dev.walk_top_units = s->flat.walk_top_units;
-    s->dev.stack_depth = std::max<uint32_t>(s->flat.depth, 1u);
+    bind_tree(s, s->base_tree());
     if (!ctx) {                                // host-only scene: keep the flattened arrays
         s->committed = true;
         return RT_OK;
     }
-    int rc = upload_scene(s, s->flat);
+    auto upload_all = [&](rt_scene* dst) -> int {
+        if (want_ref) { int rc = upload_tree(dst, TREE_REFERENCE, f_ref); if (rc) return rc; }
+        if (want_fast) { int rc = upload_tree(dst, TREE_FAST, f_fast); if (rc) return rc; }
+        return upload_tables(dst, s->flat);
+    };
+    int rc = upload_all(s);
     if (rc) return rc;
     // a multi-GPU context: the scene was flattened once; every further GPU gets the same arrays
     for (rt_context* peer : ctx->peers) {
@@ -717,13 +878,14 @@ int rt_scene_commit(rt_scene* s) {
         r->build_mode = s->build_mode;
         r->traversal = s->traversal;
         r->wide_build = s->wide_build;
-        rc = upload_scene(r, s->flat);
+        rc = upload_all(r);
         if (rc) {                              // leave no half-made copies behind: a later commit starts afresh
             const std::string why = g_last_error;
             for (rt_scene* made : s->replicas) rt_scene_destroy(made);
             s->replicas.clear();
             return fail(rc, why);
         }
+        r->flat.prim_order = s->flat.prim_order;
         r->committed = true;
     }
     // the host copies of the geometry are no longer needed
@@ -771,8 +933,8 @@ static int host_wide(const rt_scene* cs) {
     rt_scene* s = const_cast<rt_scene*>(cs);
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "the wide tree can be inspected on a committed host-only scene");
     if (!s->flat.xforms.empty()) return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
-    if (s->wide.nodes.empty()) {
-        const std::string err = build_wide_scene(s->flat.entries.data(), s->flat.n_entries(), s->wide);
+    if (s->tree().wide.nodes.empty()) {
+        const std::string err = build_wide_scene(s->flat.entries.data(), s->flat.n_entries(), s->tree().wide);
         if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
     }
     return RT_OK;
@@ -783,10 +945,10 @@ int rt_scene_wide_info(const rt_scene* s, size_t* n_nodes, size_t* n_prims, uint
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_wide_info: NULL scene");
     int rc = host_wide(s);
     if (rc) return rc;
-    if (n_nodes) *n_nodes = s->wide.n_nodes();
-    if (n_prims) *n_prims = s->wide.n_prims();
-    if (depth) *depth = s->wide.depth;
-    if (node_words) *node_words = s->wide.node_words;
+    if (n_nodes) *n_nodes = s->tree().wide.n_nodes();
+    if (n_prims) *n_prims = s->tree().wide.n_prims();
+    if (depth) *depth = s->tree().wide.depth;
+    if (node_words) *node_words = s->tree().wide.node_words;
     return RT_OK;
     RT_GUARD_END("rt_scene_wide_info")
 }
@@ -796,10 +958,10 @@ int rt_scene_get_wide(const rt_scene* s, uint32_t* nodes, size_t n_node_words, f
     if (!s || !nodes || (!prims && n_prim_floats)) return fail(RT_ERR_INVALID, "rt_scene_get_wide: NULL argument");
     int rc = host_wide(s);
     if (rc) return rc;
-    if (n_node_words != s->wide.nodes.size() || n_prim_floats != s->wide.prims.size())
+    if (n_node_words != s->tree().wide.nodes.size() || n_prim_floats != s->tree().wide.prims.size())
         return fail(RT_ERR_INVALID, "rt_scene_get_wide: size mismatch");
-    std::memcpy(nodes, s->wide.nodes.data(), n_node_words * 4);
-    if (n_prim_floats) std::memcpy(prims, s->wide.prims.data(), n_prim_floats * 4);
+    std::memcpy(nodes, s->tree().wide.nodes.data(), n_node_words * 4);
+    if (n_prim_floats) std::memcpy(prims, s->tree().wide.prims.data(), n_prim_floats * 4);
     return RT_OK;
     RT_GUARD_END("rt_scene_get_wide")
 }
@@ -972,7 +1134,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     //  - scenes walked per lane from memory: plain loop against the loop that refills idle lanes.
     //    Walks of very uneven length decide (a room with one dense mesh: refill, by 1.3-1.7x; a
     //    uniform triangle soup: plain, by 1.1-1.2x).
-    struct Form { uint32_t sweep, refill, prim_wait; };
+    struct Form { int tree; uint32_t sweep, refill, prim_wait, wide; };
     auto form_target = [&](const DevScene& d) -> uint32_t {
         if (d.sweep) return ctx->wave_target_sweep;
         if (std::getenv("RT_WAVE_TARGET") || d.ordered || staged) return ctx->wave_target;
@@ -983,35 +1145,69 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     auto seg_len_for = [&](size_t n_slots, uint32_t target) -> uint32_t {
         return std::max<uint32_t>(64u, (uint32_t)(((n_slots + target - 1) / target + 63u) / 64u * 64u));
     };
+    auto set_form = [&](const Form& f) {
+        bind_tree(s, f.tree);
+        s->dev.sweep = f.sweep; s->dev.refill = f.refill; s->dev.prim_wait = f.prim_wait; s->dev.wide = f.wide;
+        s->dev.tie = (f.tree != TREE_REFERENCE || f.wide || s->dev.octant || s->dev.ordered) ? 1u : 0u;
+    };
     if (!s->auto_tuned && !staged && !s->dev.ordered && !s->dev.wide && !std::getenv("RT_NO_AUTOTUNE")) {
         std::vector<Form> forms;
         const uint32_t wait_mem = s->env_prim_wait ? s->env_prim_wait : 8u, wait_refill = s->env_prim_wait ? s->env_prim_wait : 16u;
-        if (s->traversal == RT_TRAVERSAL_AUTO && s->dev.sweep && s->dev.lds_walk)
-            forms = {Form{1u, 0u, s->dev.prim_wait}, Form{0u, 0u, s->dev.prim_wait}};
-        else if (!s->dev.sweep && (!s->dev.lds_walk || s->dev.octant) && !std::getenv("RT_REFILL"))
-            forms = {Form{0u, 0u, wait_mem}, Form{0u, 16u, wait_refill}};
+        const bool pinned_refill = std::getenv("RT_REFILL") != nullptr;
+        if (s->traversal == RT_TRAVERSAL_AUTO) {
+            // every form that reports the reference's hits, on every tree the scene has (the base tree first:
+            // it keeps a draw)
+            const int base = s->base_tree();
+            for (int which : {base, 1 - base}) {
+                const SceneTree& t = s->trees[which];
+                if (!t.present) continue;
+                if (t.n_entries <= SWEEP_MAX_ENTRIES) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
+                if (t.lds_walk) forms.push_back(Form{which, 0u, pinned_refill ? s->env_refill : 0u, s->dev.prim_wait, 0u});
+                else if (pinned_refill) forms.push_back(Form{which, 0u, s->env_refill, s->dev.prim_wait, 0u});
+                else { forms.push_back(Form{which, 0u, 0u, wait_mem, 0u}); forms.push_back(Form{which, 0u, 16u, wait_refill, 0u}); }
+            }
+            // the wide walk over the surface-area trees, for scenes that are walked from memory
+            if (s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && !s->trees[TREE_FAST].lds_walk &&
+                !std::getenv("RT_AUTO_NO_WIDE")) {
+                const int was = s->cur;
+                bind_tree(s, TREE_FAST);
+                const int wrc = ensure_wide_tree(s);
+                bind_tree(s, was);
+                if (wrc == RT_OK) forms.push_back(Form{TREE_FAST, 0u, pinned_refill ? s->env_refill : 16u, s->dev.prim_wait, 1u});
+                else if (wrc != RT_ERR_UNSUPPORTED) return wrc;
+            }
+        } else if (!s->dev.sweep && (!s->dev.lds_walk || s->dev.octant) && !pinned_refill) {
+            forms = {Form{s->cur, 0u, 0u, wait_mem, 0u}, Form{s->cur, 0u, 16u, wait_refill, 0u}};
+        }
+        if (forms.size() == 1) { set_form(forms[0]); forms.clear(); }
         size_t best = 0;
         float best_ms = 0.0f;
         // an error return from the probe leaves the scene on the form it had
         struct Restore {
-            DevScene& d;
+            rt_scene* s;
             Form was;
+            uint32_t tie;
             bool keep = false;
-            ~Restore() { if (!keep) { d.sweep = was.sweep; d.refill = was.refill; d.prim_wait = was.prim_wait; } }
-        } restore{s->dev, Form{s->dev.sweep, s->dev.refill, s->dev.prim_wait}};
+            ~Restore() {
+                if (keep) return;
+                bind_tree(s, was.tree);
+                s->dev.sweep = was.sweep; s->dev.refill = was.refill; s->dev.prim_wait = was.prim_wait; s->dev.wide = was.wide;
+                s->dev.tie = tie;
+            }
+        } restore{s, Form{s->cur, s->dev.sweep, s->dev.refill, s->dev.prim_wait, s->dev.wide}, s->dev.tie};
+        const bool whole_batch = s->trees[s->base_tree()].lds_walk;
         for (size_t f = 0; f < forms.size(); f++) {
-            s->dev.sweep = forms[f].sweep; s->dev.refill = forms[f].refill; s->dev.prim_wait = forms[f].prim_wait;
+            set_form(forms[f]);
             BatchGeom g;
             g.width = p->width; g.height = p->height;
             g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
             g.tiles_x = tiles_x;
             g.tile_base = 0;
-            // Small scenes (sweep against the walk out of LDS) are cheap and the two forms lie close
+            // Small scenes (sweep against the walk out of LDS) are cheap and the forms lie close
             // together, so the probe is a whole batch of the frame, cut into the segments the form
             // really gets (the sweep fills its groups of 128 rays worse from short segments).  Big
             // scenes: at most 4 Mi paths, in segments as long as the real batches' (what the refill
             // draws on) but not over 512, so that the probe still spreads over every wave slot.
-            const bool whole_batch = s->dev.lds_walk != 0;
             const size_t nt = whole_batch ? tiles_per_batch : std::min<size_t>(tiles_per_batch, 4096);
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin;
@@ -1061,20 +1257,18 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
             if (std::getenv("RT_AUTOTUNE_LOG"))       // the probe's timings on stderr
-                std::fprintf(stderr, "[rt probe] sweep %u refill %u prim_wait %u: %.3f ms (%u slots in %u segments, %d pipelines)\n",
-                             forms[f].sweep, forms[f].refill, forms[f].prim_wait, ms, g.n_slots, g.n_seg, probe_pipes);
+                std::fprintf(stderr, "[rt probe] tree %d sweep %u wide %u refill %u prim_wait %u: %.3f ms (%u slots in %u segments, %d pipelines)\n",
+                             forms[f].tree, forms[f].sweep, forms[f].wide, forms[f].refill, forms[f].prim_wait, ms, g.n_slots, g.n_seg, probe_pipes);
             // The probe is one batch per pipeline, started together and drained to the end, and that flatters
             // the walk: in the frame itself batch follows batch and the sweep's long-lived waves (one per wave
             // slot) lose less to the drain than here.  Measured on the plane Cornell box, a 1/8 share of the
-            // frame: probe 11.4 ms sweep against 10.8-11.4 ms walk, frame 37.6 ms against 40.8 ms.  The walk
-            // therefore has to win the probe by a tenth to be taken (where it really wins -- objects scattered
-            // under a sky -- it wins by 1.2-1.5x).
-            const float margin = (f > 0 && forms[0].sweep && !forms[f].sweep) ? 0.9f : 1.0f;
+            // frame: probe 11.4 ms sweep against 10.8-11.4 ms walk, frame 37.6 ms against 40.8 ms.  A form that
+            // is not a sweep therefore has to beat a sweep by a tenth to be taken (where the walks really win
+            // -- objects scattered under a sky, the surface-area trees -- they win by 1.2-1.5x).
+            const float margin = (f > 0 && forms[best].sweep && !forms[f].sweep) ? 0.9f : 1.0f;
             if (f == 0 || ms < best_ms * margin) { best = f; best_ms = ms; }
         }
-        if (!forms.empty()) {
-            s->dev.sweep = forms[best].sweep; s->dev.refill = forms[best].refill; s->dev.prim_wait = forms[best].prim_wait;
-        }
+        if (!forms.empty()) set_form(forms[best]);
         restore.keep = true;
         s->auto_tuned = true;
     }
@@ -1097,25 +1291,40 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
     }
 
     hipStream_t st0 = ctx->pipes[0].stream;
+    const hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
     struct Span { size_t e0, e1; int what; };
     std::vector<Span> spans[MAX_PIPES];
     size_t ev_used[MAX_PIPES] = {};
     double ms_by_kind[2] = {0.0, 0.0};
+    // the closest-hit kernels of the pipelines overlap: besides their summed durations, the span from
+    // the first start to the last end (both measured from the call's begin event)
+    double first_start_ms = 1e300, last_end_ms = 0.0;
     auto fold_spans = [&]() -> int {           // needs every stream to be idle
         for (int k = 0; k < MAX_PIPES; k++) {
             for (const Span& sp : spans[k]) {
                 float m = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&m, ctx->pipes[k].events[sp.e0], ctx->pipes[k].events[sp.e1]));
                 ms_by_kind[sp.what] += m;
+                if (sp.what == 0) {
+                    float a = 0.0f, b = 0.0f;
+                    HIP_TRY(hipEventElapsedTime(&a, ev_begin, ctx->pipes[k].events[sp.e0]));
+                    HIP_TRY(hipEventElapsedTime(&b, ev_begin, ctx->pipes[k].events[sp.e1]));
+                    first_start_ms = std::min(first_start_ms, (double)a);
+                    last_end_ms = std::max(last_end_ms, (double)b);
+                }
             }
             spans[k].clear();
             ev_used[k] = 0;
         }
         return RT_OK;
     };
+    constexpr size_t CLOCK_SLOTS = 4096;       // launches whose clock stamps are kept (a ring)
+    if (profile && !staged) {
+        HIP_TRY(ctx->clock_stamps.ensure(CLOCK_SLOTS * 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(ctx->clock_stamps.p, 0, CLOCK_SLOTS * 4 * sizeof(unsigned long long), st0));
+    }
 
     HIP_TRY(hipMemsetAsync(ctx->totals.p, 0, sizeof(Totals), st0));
-    const hipEvent_t ev_begin = ctx->ev_begin, ev_end = ctx->ev_end;
     HIP_TRY(hipEventRecord(ev_begin, st0));
     if (n_pipes > 1) {                         // the other streams start after whatever precedes the call
         HIP_TRY(hipEventRecord(ctx->ev_fork, st0));
@@ -1194,6 +1403,8 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 return lr;
             };
             bind();
+            if (profile && !staged)
+                rb.clock_stamps = (unsigned long long*)ctx->clock_stamps.p + (trace_launches % CLOCK_SLOTS) * 4;
             if (!staged) {
                 int lr = mark(0, [&]() {
                     return launch_path(cfg, s->dev, *cam, g, p->seed, rb, p->max_bounces, p->t_min, p->sky_intensity);
@@ -1253,7 +1464,22 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         if (rc) return rc;
         stats->ms_trace = ms_by_kind[0];
         stats->ms_shade = ms_by_kind[1];
+        stats->ms_kernel_span = last_end_ms > first_start_ms ? last_end_ms - first_start_ms : 0.0;
+        stats->ms_render_min = ms;
+        if (profile && !staged && trace_launches) {    // the shader clock the per-batch kernels ran at
+            const size_t n = (size_t)std::min<uint64_t>(trace_launches, CLOCK_SLOTS);
+            std::vector<unsigned long long> w(n * 4);
+            HIP_TRY(hipMemcpy(w.data(), ctx->clock_stamps.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            double cyc = 0.0, ref = 0.0;
+            for (size_t i = 0; i < n; i++)
+                if (w[i * 4 + 3] > w[i * 4 + 1] && w[i * 4 + 2] > w[i * 4]) {
+                    cyc += (double)(w[i * 4 + 2] - w[i * 4]);
+                    ref += (double)(w[i * 4 + 3] - w[i * 4 + 1]);
+                }
+            if (ref > 0.0) stats->shader_clock_ghz = cyc / ref * 0.1;      // the reference counter runs at 100 MHz
+        }
         stats->n_devices = 1;
+        stats->tree = s->cur == TREE_REFERENCE ? RT_TREE_REFERENCE : RT_TREE_SAH;
         const DevScene& d = s->dev;            // the form the launches above took
         stats->kernel_form = d.wide ? (d.refill && !staged ? RT_FORM_WIDE_REFILL : RT_FORM_WIDE)
                              : d.ordered ? RT_FORM_ORDERED
@@ -1325,84 +1551,125 @@ int rt_render_multi_device(rt_scene* s, const rt_camera* cam, const rt_render_pa
     const int n = 1 + (int)root->peers.size();
     if ((int)s->replicas.size() != n - 1) return fail(RT_ERR_STATE, "rt_render_multi: the scene was not committed on this context");
     const size_t n_floats = (size_t)p->width * p->height * 3;
+    const size_t frame_bytes = n_floats * sizeof(float);
+    auto ctx_of = [&](int r) { return r == 0 ? root : root->peers[(size_t)r - 1]; };
 
-    // every GPU renders its share on a host thread of its own
+    // Every GPU renders its share into a zeroed frame of its own -- the root too: the caller's buffer
+    // is touched only after every GPU has succeeded, so a call that fails can be repeated -- on a host
+    // thread of its own (the peers' threads belong to the context).
     struct Worker { int rc = RT_OK; std::string err; rt_stats st; };
     std::vector<Worker> work((size_t)n);
     auto job = [&](int r) {
         Worker& w = work[(size_t)r];
         std::memset(&w.st, 0, sizeof(w.st));
-        rt_scene* sc = r == 0 ? s : s->replicas[(size_t)r - 1];
-        rt_context* ctx = sc->ctx;
-        rt_render_params pr = *p;
-        w.rc = rt_partition((uint32_t)n, (uint32_t)r, &pr);
-        void* buf = d_accum;
-        if (w.rc == RT_OK && r > 0) {          // a peer accumulates into its own zeroed frame
-            hipError_t e = hipSetDevice(ctx->device);
-            if (e == hipSuccess) e = ctx->frame.ensure(n_floats * sizeof(float));
-            if (e == hipSuccess) e = hipMemsetAsync(ctx->frame.p, 0, n_floats * sizeof(float), ctx->stream);
-            if (e != hipSuccess) w.rc = fail(RT_ERR_DEVICE, std::string("rt_render_multi: frame buffer: ") + hipGetErrorString(e));
-            buf = ctx->frame.p;
+        try {
+            rt_scene* sc = r == 0 ? s : s->replicas[(size_t)r - 1];
+            rt_context* ctx = sc->ctx;
+            rt_render_params pr = *p;
+            w.rc = rt_partition((uint32_t)n, (uint32_t)r, &pr);
+            if (w.rc == RT_OK) {
+                hipError_t e = hipSetDevice(ctx->device);
+                if (e == hipSuccess) e = ctx->frame.ensure(frame_bytes);
+                if (e == hipSuccess) e = hipMemsetAsync(ctx->frame.p, 0, frame_bytes, ctx->stream);
+                if (e != hipSuccess) w.rc = fail(RT_ERR_DEVICE, std::string("rt_render_multi: frame buffer: ") + hipGetErrorString(e));
+            }
+            if (w.rc == RT_OK && pr.sample_begin < pr.sample_end) w.rc = rt_render_device(sc, cam, &pr, ctx->frame.p, &w.st);
+            else if (w.rc == RT_OK) w.rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? RT_OK : fail(RT_ERR_DEVICE, "rt_render_multi: synchronize");
+        } catch (const std::bad_alloc&) {
+            w.rc = fail(RT_ERR_NOMEM, "rt_render_multi: out of host memory");
+        } catch (...) {
+            w.rc = fail(RT_ERR_INVALID, "rt_render_multi: exception in a GPU's host thread");
         }
-        if (w.rc == RT_OK && pr.sample_begin < pr.sample_end) w.rc = rt_render_device(sc, cam, &pr, buf, &w.st);
-        else if (w.rc == RT_OK && r > 0) w.rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? RT_OK : fail(RT_ERR_DEVICE, "rt_render_multi: synchronize");
         if (w.rc != RT_OK) w.err = g_last_error;   // the message lives in this thread
     };
-    {
-        std::vector<std::thread> threads;
-        for (int r = 1; r < n; r++) threads.emplace_back(job, r);
-        job(0);
-        for (std::thread& t : threads) t.join();
-    }
+    for (int r = 1; r < n; r++) root->workers[(size_t)r - 1]->submit([&job, r]() { job(r); });
+    job(0);
+    for (int r = 1; r < n; r++) root->workers[(size_t)r - 1]->wait();
     for (const Worker& w : work)
         if (w.rc != RT_OK) return fail(w.rc, w.err);
 
-    // the one collective: sum the frames to the root (every render above has drained its stream)
+    // combine the frames on the root (every render above has drained its stream), then add the sum
+    // to the caller's buffer
     const auto t0 = std::chrono::steady_clock::now();
-    if (n > 1 && !root->comms.empty()) {
+    uint32_t rccl_ranks = 0;
+    int reduce_mode = root->reduce_mode;
+    HIP_TRY(hipSetDevice(root->device));
+    if (n > 1 && !root->comms.empty() && reduce_mode == RT_REDUCE_RCCL) {
+        // the one collective: ncclReduce(sum, f32) to the root, in place there
         ncclResult_t nr = ncclGroupStart();
         for (int r = 0; r < n && nr == ncclSuccess; r++) {
-            rt_context* ctx = r == 0 ? root : root->peers[(size_t)r - 1];
-            const void* send = r == 0 ? d_accum : ctx->frame.p;
-            nr = ncclReduce(send, d_accum, n_floats, ncclFloat, ncclSum, 0, root->comms[(size_t)r], ctx->stream);
+            rt_context* ctx = ctx_of(r);
+            nr = ncclReduce(ctx->frame.p, root->frame.p, n_floats, ncclFloat, ncclSum, 0, root->comms[(size_t)r], ctx->stream);
         }
         const ncclResult_t ne = ncclGroupEnd();
         if (nr == ncclSuccess) nr = ne;
         if (nr != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("rt_render_multi: ncclReduce: ") + ncclGetErrorString(nr));
-        for (int r = 0; r < n; r++) {
-            rt_context* ctx = r == 0 ? root : root->peers[(size_t)r - 1];
+        for (int r = n - 1; r >= 0; r--) {
+            rt_context* ctx = ctx_of(r);
             HIP_TRY(hipSetDevice(ctx->device));
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
-    } else if (n == 1 && !root->comms.empty()) {
+        int count = 0;
+        if (ncclCommCount(root->comms[0], &count) == ncclSuccess) rccl_ranks = (uint32_t)count;
+    } else if (n == 1 && !root->comms.empty() && reduce_mode == RT_REDUCE_RCCL) {
         // one GPU: the same call, a reduce over one rank (in place)
-        const ncclResult_t nr = ncclReduce(d_accum, d_accum, n_floats, ncclFloat, ncclSum, 0, root->comms[0], root->stream);
+        const ncclResult_t nr = ncclReduce(root->frame.p, root->frame.p, n_floats, ncclFloat, ncclSum, 0, root->comms[0], root->stream);
         if (nr != ncclSuccess) return fail(RT_ERR_DEVICE, std::string("rt_render_multi: ncclReduce: ") + ncclGetErrorString(nr));
-        HIP_TRY(hipSetDevice(root->device));
-        HIP_TRY(hipStreamSynchronize(root->stream));
-    } else if (n > 1) {
-        // the workers share one GPU: add their frames in rank order
-        HIP_TRY(hipSetDevice(root->device));
-        for (int r = 1; r < n; r++)
-            if (launch_add_frame(root->cfg(), d_accum, root->peers[(size_t)r - 1]->frame.p, n_floats))
+        int count = 0;
+        if (ncclCommCount(root->comms[0], &count) == ncclSuccess) rccl_ranks = (uint32_t)count;
+    } else if (n > 1 && reduce_mode == RT_REDUCE_ORDERED) {
+        // strict order: every peer's frame is copied to the root and added there, rank by rank, on the
+        // root's stream (two staging halves, so the copy of rank r + 1 runs under the add of rank r)
+        HIP_TRY(root->stage.ensure(2 * frame_bytes));
+        hipStream_t copy_stream = root->pipes[1].stream;
+        for (int r = 1; r < n; r++) {
+            rt_context* peer = ctx_of(r);
+            char* half = (char*)root->stage.p + (size_t)(r & 1) * frame_bytes;
+            // the half is free once the add of rank r - 2 has run
+            if (r >= 3) HIP_TRY(hipStreamWaitEvent(copy_stream, root->pipes[(r & 1)].accum_done, 0));
+            HIP_TRY(hipMemcpyPeerAsync(half, root->device, peer->frame.p, peer->device, frame_bytes, copy_stream));
+            HIP_TRY(hipEventRecord(root->pipes[2 + (r & 1)].joined, copy_stream));
+            HIP_TRY(hipStreamWaitEvent(root->stream, root->pipes[2 + (r & 1)].joined, 0));
+            if (launch_add_frame(root->cfg(), root->frame.p, half, n_floats))
                 return fail(RT_ERR_DEVICE, "rt_render_multi: add launch failed");
-        HIP_TRY(hipStreamSynchronize(root->stream));
+            HIP_TRY(hipEventRecord(root->pipes[(r & 1)].accum_done, root->stream));
+        }
+    } else if (n > 1) {
+        // the workers share one GPU (RCCL refuses two ranks on a device): add their frames in rank order
+        reduce_mode = RT_REDUCE_ORDERED;
+        for (int r = 1; r < n; r++)
+            if (launch_add_frame(root->cfg(), root->frame.p, ctx_of(r)->frame.p, n_floats))
+                return fail(RT_ERR_DEVICE, "rt_render_multi: add launch failed");
     }
     HIP_TRY(hipSetDevice(root->device));
+    if (launch_add_frame(root->cfg(), d_accum, root->frame.p, n_floats)) return fail(RT_ERR_DEVICE, "rt_render_multi: add launch failed");
+    HIP_TRY(hipStreamSynchronize(root->stream));
     const double ms_reduce = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (stats) {
         *stats = work[0].st;
-        for (int r = 1; r < n; r++) {
+        stats->ms_render_min = work[0].st.ms_render;
+        stats->slowest_device = 0;
+        for (int r = 0; r < n; r++) {
             const rt_stats& o = work[(size_t)r].st;
+            if (r < RT_STATS_MAX_DEVICES) {
+                stats->device_ms_render[r] = (float)o.ms_render;
+                stats->device_form[r] = (uint8_t)o.kernel_form;
+                stats->device_tree[r] = (uint8_t)o.tree;
+            }
+            if (r == 0) continue;
             stats->rays_traced += o.rays_traced; stats->paths += o.paths;
             stats->box_tests += o.box_tests; stats->tri_tests += o.tri_tests; stats->sph_tests += o.sph_tests;
             stats->trace_launches += o.trace_launches;
-            stats->ms_render = std::max(stats->ms_render, o.ms_render);
+            if (o.ms_render > stats->ms_render) { stats->ms_render = o.ms_render; stats->slowest_device = (uint32_t)r; }
+            if (o.paths) stats->ms_render_min = std::min(stats->ms_render_min, o.ms_render);
             stats->ms_trace = std::max(stats->ms_trace, o.ms_trace);
             stats->ms_shade = std::max(stats->ms_shade, o.ms_shade);
+            stats->ms_kernel_span = std::max(stats->ms_kernel_span, o.ms_kernel_span);
         }
         stats->ms_reduce = ms_reduce;
         stats->n_devices = (uint32_t)n;
+        stats->rccl_ranks = rccl_ranks;
+        stats->reduce_mode = (uint32_t)reduce_mode;
     }
     return RT_OK;
     RT_GUARD_END("rt_render_multi")

@@ -1598,6 +1598,10 @@ struct PathBuffers {
     float4* Lbuf;
     uint32_t* segcnt;          // [max_bounces * n_seg]: live rays entering each depth (ray totals)
     Totals* totals;            // visit counters (diagnostic builds)
+    // Profiled renders only (else null): the wave of segment 0 stores the shader-cycle counter and the
+    // constant-rate (100 MHz) counter when it starts and when it ends, four words per launch; the
+    // ratio of the differences is the shader clock the chip held while this very kernel ran.
+    unsigned long long* clock_stamps;
 };
 
 __device__ __forceinline__ void stage_fence() {
@@ -1631,6 +1635,11 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
     const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
     const uint32_t base = seg * g.seg_len;
+    unsigned long long clk0 = 0, ref0 = 0;
+    if (seg == 0 && pb.clock_stamps) {         // (wave-uniform; one wave of the launch)
+        clk0 = __builtin_amdgcn_s_memtime();
+        ref0 = __builtin_amdgcn_s_memrealtime();
+    }
     uint32_t n = raygen_segment(cam, g, seed_lo, seed_hi, pb.A0, pb.B0, pb.C0, base, lane);
     Counts cnt{0, 0, 0};
     for (uint32_t d = 0; d < max_bounces; d++) {
@@ -1656,6 +1665,13 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
 #ifdef RT_STAMPS
     if (lane == 0) write_stamp(stamp_slot, seg, stamp_t0, n);
 #endif
+    if (seg == 0 && pb.clock_stamps) {
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            pb.clock_stamps[0] = clk0; pb.clock_stamps[1] = ref0;
+            pb.clock_stamps[2] = clk1; pb.clock_stamps[3] = ref1;
+        }
+    }
 #ifdef RT_UTIL
     atomicAdd(&pb.totals->box, (unsigned long long)cnt.box);
     atomicAdd(&pb.totals->tri, (unsigned long long)cnt.tri);
@@ -1767,6 +1783,7 @@ static inline PathBuffers path_buffers(const RenderBuffers& rb) {
     pb.Lbuf = (float4*)rb.Lbuf;
     pb.segcnt = rb.segcnt;
     pb.totals = rb.totals;
+    pb.clock_stamps = rb.clock_stamps;
     return pb;
 }
 

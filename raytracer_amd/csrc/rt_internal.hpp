@@ -297,6 +297,7 @@ struct RenderBuffers {
     uint32_t* qcnt;        // [3 * n_seg] queue lengths of the current depth
     Totals* totals;
     size_t capacity;       // paths
+    unsigned long long* clock_stamps = nullptr;   // profiled renders: four words for this launch's clock stamps (else null)
 };
 
 struct LaunchCfg {

@@ -24,6 +24,12 @@ pub const RT_WIDE_BUILD_COLLAPSE: c_int = 0;
 pub const RT_WIDE_BUILD_DEVICE: c_int = 1;
 pub const RT_BUILD_REFERENCE: c_int = 0;
 pub const RT_BUILD_SAH: c_int = 1;
+pub const RT_BUILD_AUTO: c_int = 2;
+pub const RT_TREE_REFERENCE: u32 = 0;
+pub const RT_TREE_SAH: u32 = 1;
+pub const RT_REDUCE_RCCL: c_int = 0;
+pub const RT_REDUCE_ORDERED: c_int = 1;
+pub const RT_STATS_MAX_DEVICES: usize = 16;
 pub const RT_CACHE_OFF: c_int = 0;
 pub const RT_CACHE_STORED: c_int = 1;
 pub const RT_CACHE_LOADED: c_int = 2;
@@ -71,6 +77,9 @@ pub struct rt_stats {
     pub rays_traced: u64, pub paths: u64, pub box_tests: u64, pub tri_tests: u64, pub sph_tests: u64,
     pub trace_launches: u64, pub ms_render: f64, pub ms_trace: f64, pub ms_shade: f64,
     pub ms_reduce: f64, pub n_devices: u32, pub kernel_form: u32,
+    pub tree: u32, pub rccl_ranks: u32, pub ms_kernel_span: f64, pub ms_render_min: f64,
+    pub slowest_device: u32, pub reduce_mode: u32, pub shader_clock_ghz: f64,
+    pub device_ms_render: [f32; 16], pub device_form: [u8; 16], pub device_tree: [u8; 16],
 }
 pub enum rt_context {}
 pub enum rt_scene {}
@@ -84,6 +93,7 @@ extern "C" {
     pub fn rt_context_create(device_id: c_int, out: *mut *mut rt_context) -> c_int;
     pub fn rt_context_create_multi(n_dev: c_int, dev_ids: *const c_int, out: *mut *mut rt_context) -> c_int;
     pub fn rt_context_num_devices(ctx: *const rt_context) -> c_int;
+    pub fn rt_context_set_reduce(ctx: *mut rt_context, mode: c_int) -> c_int;
     pub fn rt_context_destroy(ctx: *mut rt_context);
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_context_stream(ctx: *mut rt_context) -> *mut c_void;

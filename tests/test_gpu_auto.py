@@ -1,0 +1,97 @@
+"""RT_BUILD_AUTO + RT_TRAVERSAL_AUTO (the defaults): the scene holds the reference's trees and the
+surface-area trees, and its first render times every form of the closest-hit loop that reports the
+reference's hits -- on either tree, the wide walk included -- and keeps the fastest.  Whatever it
+keeps, the frame is the strict reference-order frame bit for bit and rt_trace reports the oracle's
+primitive and t on every ray."""
+import numpy as np
+import pytest
+
+from helpers import asset, assert_hits_equal, mirror, product_camera, random_rays, random_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _strict_frame(rt, ctx, osc, cam, p):
+    sc = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=rt.BUILD_REFERENCE)
+    sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+    img, st = sc.render(cam, p)
+    assert rt.TREE_NAMES[st["tree"]] == "reference"
+    sc.close()
+    return img, st
+
+
+@pytest.mark.parametrize("name", ["cornell_box_plane.obj", "cornell_box.obj", "world1", "thing.obj"])
+def test_auto_keeps_the_reference_frame(rt, ob, ctx, name, capfd, monkeypatch):
+    monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
+    osc = {"world1": ob.Scene.world1, "thing.obj": lambda: ob.Scene.world2(asset("thing.obj"), 1)}.get(
+        name, lambda: ob.Scene.cornell_box(asset(name)))()
+    w, h, spp, depth = 256, 192, 32, 6
+    cam = product_camera(rt, osc, w, h)
+    p = rt.Scene.params(w, h, spp, depth, osc.sky)
+    want, st_want = _strict_frame(rt, ctx, osc, cam, p)
+    sc = mirror(rt, ctx, osc)                                  # the defaults: both trees, every form a candidate
+    rays = osc.record_rays(96, 96, 2, 6, cap=80000)
+    oracle, _ = osc.trace(rays)
+    assert_hits_equal(sc.trace(rays), oracle)                  # before the first render: the base form
+    capfd.readouterr()
+    img, st = sc.render(cam, p)
+    probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    with capfd.disabled():
+        print(f"\n{name}: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree: "
+              + "; ".join(l.split("] ")[1].split(" (")[0] for l in probes))
+    has_mesh = name != "world1"
+    assert len(probes) >= 2 if has_mesh else not probes        # (spheres only: one tree, one form that applies)
+    assert any("tree 1" in l for l in probes) == has_mesh
+    assert st["rays_traced"] == st_want["rays_traced"]
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    assert_hits_equal(sc.trace(rays), oracle)                  # after it: the form the probe kept
+    again, st2 = sc.render(cam, p)                             # and no second probe
+    assert not [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    assert st2["kernel_form"] == st["kernel_form"] and st2["tree"] == st["tree"]
+    assert np.array_equal(again.view(np.uint32), want.view(np.uint32))
+    # the explicit modes stay on the reference's trees
+    sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+    _, st3 = sc.render(cam, p)
+    assert rt.TREE_NAMES[st3["tree"]] == "reference"
+    sc.close()
+
+
+def test_auto_on_a_scene_walked_from_memory(rt, ob, ctx, capfd, monkeypatch):
+    """Trees that do not fit LDS: the candidates are the plain and the refilled walk on both trees and
+    the wide walk over the surface-area trees."""
+    monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
+    mats, objects, _ = random_scene(ob, 19, n_spheres=60, n_meshes=3, tris_per_mesh=4000, extent=8.0)
+    osc = ob.Scene.from_description(mats, objects, ob.ROOT_BVH)
+    w, h, spp, depth = 192, 160, 8, 5
+    cam = product_camera(rt, osc, w, h)
+    p = rt.Scene.params(w, h, spp, depth, 1.0)
+    want, st_want = _strict_frame(rt, ctx, osc, cam, p)
+    sc = mirror(rt, ctx, osc)
+    capfd.readouterr()
+    img, st = sc.render(cam, p)
+    probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    with capfd.disabled():
+        print(f"\nrandom scene: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree: "
+              + "; ".join(l.split("] ")[1].split(" (")[0] for l in probes))
+    assert len(probes) == 5 and sum("wide 1" in l for l in probes) == 1
+    assert st["rays_traced"] == st_want["rays_traced"] and np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    rays = random_rays(ob, 5, 150000, -10.0, 10.0)
+    oracle, _ = osc.trace(rays)
+    assert_hits_equal(sc.trace(rays), oracle)
+    sc.close()
+
+
+def test_profiled_render_reports_its_own_clock_and_span(rt, ob, ctx):
+    osc = ob.Scene.cornell_box(asset("cornell_box_plane.obj"))
+    sc = mirror(rt, ctx, osc)
+    w, h, spp = 512, 512, 64
+    cam = product_camera(rt, osc, w, h)
+    sc.render(cam, rt.Scene.params(w, h, spp, 6, osc.sky))     # the probe
+    _, st = sc.render(cam, rt.Scene.params(w, h, spp, 6, osc.sky, flags=rt.RENDER_PROFILE))
+    print(f"clock {st['shader_clock_ghz']:.3f} GHz, kernels {st['ms_trace']:.2f} ms summed, {st['ms_kernel_span']:.2f} ms "
+          f"from first start to last end, call {st['ms_render']:.2f} ms")
+    assert 0.8 < st["shader_clock_ghz"] < 3.2
+    assert 0 < st["ms_kernel_span"] <= st["ms_render"] and st["ms_kernel_span"] <= st["ms_trace"] * 1.001 + 0.05
+    _, st0 = sc.render(cam, rt.Scene.params(w, h, spp, 6, osc.sky))
+    assert st0["shader_clock_ghz"] == 0 and st0["ms_kernel_span"] == 0
+    sc.close()

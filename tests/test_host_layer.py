@@ -32,7 +32,7 @@ def test_struct_layouts_match_header(rt):
     assert rt.material_dt.itemsize == 24 and rt.sphere_dt.itemsize == 20
     assert rt.triangle_dt.itemsize == 52 and rt.ray_dt.itemsize == 24
     assert rt.hit_dt.itemsize == 40 and rt.camera_dt.itemsize == 76
-    assert ctypes.sizeof(rt.RenderParams) == 80 and ctypes.sizeof(rt.Stats) == 88
+    assert ctypes.sizeof(rt.RenderParams) == 80 and ctypes.sizeof(rt.Stats) == 224
 
 
 def test_no_gpu_fails_loudly(rt):
@@ -883,5 +883,5 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
     sizes = [int(v) for v in out.stdout.splitlines()[0].split()]
-    assert sizes == [24, 20, 52, 24, 40, 76, 80, 88]           # the layouts the Python and Rust stubs assume
+    assert sizes == [24, 20, 52, 24, 40, 76, 80, 224]           # the layouts the Python and Rust stubs assume
     assert out.stdout.splitlines()[1].strip()                  # a message, not an empty string
