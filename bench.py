@@ -85,15 +85,16 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def pmc_record(workload, build):
+def pmc_record(workload, key):
     """Per-ray hardware counts of this workload's per-batch kernel from the committed rocprofv3 PMC
     passes (rocprofv3 cannot run inside this process): HBM bytes per ray ((2*FETCH_SIZE + WRITE_SIZE)
-    KiB, the gfx950 correction for 16-byte-per-lane streams), vector instructions per ray, the clock the
-    chip held.  They are properties of the kernel and the workload, so multiplied by the rate measured
-    in THIS run they give this run's HBM and issue rates.  None when there is no record."""
+    KiB, the gfx950 correction for 16-byte-per-lane streams), vector instructions per ray.  They are
+    properties of the kernel and the workload, so multiplied by the rate (and divided by the clock)
+    measured in THIS run they give this run's HBM and issue rates.  Records are keyed
+    <workload>/<tree>/<kernel form>.  None when there is no record."""
     try:
         with open(PMC_FILE) as f:
-            rec = json.load(f)["records"].get(f"{workload}/{build}")
+            rec = json.load(f)["records"].get(f"{workload}/{key}")
     except (OSError, KeyError, ValueError):
         return None
     if rec is not None:
@@ -101,7 +102,7 @@ def pmc_record(workload, build):
     return rec
 
 
-def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray, tests, extra):
+def roofline(workload, key, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray, tests, extra, clock_ghz=None):
     """The bound of the dominant kernel as a fraction <= 1.  Three candidates, all from measured
     counts: HBM (PMC bytes per ray x measured rays/s against the 8 TB/s peak), vector-instruction
     issue (PMC instructions per ray x measured rays/s, priced at the SIMD cycles per instruction this
@@ -112,24 +113,29 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
     out = {"kernel": extra.pop("kernel"), "algorithmic": {"bytes_per_ray": round(bytes_per_ray, 1), "GB/s": round(algo_gbs, 1) if algo_gbs else None,
                                                          "of_hbm_peak": round(algo_gbs / (HBM_PEAK_GBS * n_gpus), 4) if algo_gbs else None,
                                                          "tests_per_ray": tests}}
-    rec = pmc_record(workload, build)
+    rec = pmc_record(workload, key)
     if rec is None:
         out.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": None, "traffic": None,
-                    "note": f"no PMC record for {workload}/{build} in profiles/pmc_workloads.json: only the algorithmic rate is known"})
+                    "note": f"no PMC record for {workload}/{key} in profiles/pmc_workloads.json: only the algorithmic rate is known"})
         out.update(extra)
         return out
     per_gpu = rays_per_s / n_gpus
     hbm_gbs = rec["hbm_bytes_per_ray"] * per_gpu / 1e9
     hbm_frac = hbm_gbs / HBM_PEAK_GBS
     cyc = rec["simd_cycles_per_valu_inst"]
-    issue_rate = rec["valu_insts_per_ray"] * per_gpu / (N_SIMDS * rec["clock_ghz"] * 1e9)    # per SIMD cycle
+    # the clock of THIS run (one wave of every launch reads the cycle counter and the 100 MHz counter at its
+    # start and end: rt_stats.shader_clock_ghz); the profiled run's lower clock only where that is missing
+    run_clock = clock_ghz if clock_ghz else rec["clock_ghz"]
+    issue_rate = rec["valu_insts_per_ray"] * per_gpu / (N_SIMDS * run_clock * 1e9)    # per SIMD cycle
     issue_peak = 1.0 / cyc
     issue_frac = issue_rate / issue_peak
     out["hbm"] = {"achieved_GB/s": round(hbm_gbs, 1), "peak_GB/s": HBM_PEAK_GBS, "frac": round(hbm_frac, 4),
                   "bytes_per_ray": round(rec["hbm_bytes_per_ray"], 1)}
     out["valu_issue"] = {"achieved_inst_per_simd_cycle": round(issue_rate, 4), "peak_inst_per_simd_cycle": round(issue_peak, 4),
                          "frac": round(issue_frac, 4), "insts_per_ray": round(rec["valu_insts_per_ray"], 1),
-                         "active_lanes_per_inst": rec.get("active_lanes"), "clock_ghz": rec["clock_ghz"]}
+                         "active_lanes_per_inst": rec.get("active_lanes"), "clock_ghz": round(run_clock, 3),
+                         "clock_source": "measured in this run (rt_stats.shader_clock_ghz)" if clock_ghz else "the profiled run's",
+                         "clock_ghz_profiled_run": rec["clock_ghz"]}
     # third candidate: the CUs' address units (TA), through which every vector memory instruction goes.
     # TA_TA_BUSY over the profiled run gives busy cycles per ray; at this run's rate that is the share
     # of time the units are busy.  (Priced instead at the 16 CU cycles a wave-wide access takes at
@@ -137,7 +143,7 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
     vmem_frac = None
     if rec.get("ta_busy") is not None and rec.get("mrays_profiled"):
         vmem_frac = rec["ta_busy"] * per_gpu / (rec["mrays_profiled"] * 1e6)
-        vmem_rate = rec["vmem_insts_per_ray"] * per_gpu / (N_CUS * rec["clock_ghz"] * 1e9)      # per CU cycle
+        vmem_rate = rec["vmem_insts_per_ray"] * per_gpu / (N_CUS * run_clock * 1e9)      # per CU cycle
         out["address_unit"] = {"busy_share": round(vmem_frac, 4), "busy_share_profiled": rec["ta_busy"],
                                "vmem_insts_per_ray": round(rec["vmem_insts_per_ray"], 2),
                                "vmem_insts_per_cu_cycle": round(vmem_rate, 4),
@@ -156,6 +162,8 @@ def roofline(workload, build, form, rays_per_s, n_gpus, algo_gbs, bytes_per_ray,
     out["pmc"] = {"file": "profiles/pmc_workloads.json", "profiled_form": rec.get("form"), "this_run_form": form,
                   "git_sha": rec.get("git_sha"), "source_hash": rec.get("source_hash"), "stale": rec["stale"],
                   "per_gpu": n_gpus > 1}
+    if rec.get("stages"):                      # the staged launches' counters: which stage the instructions belong to
+        out["stages"] = rec["stages"]
     if rec["stale"] or (rec.get("form") and rec.get("form") != form):
         out["note"] = "the PMC record was taken on other kernel sources or another kernel form than this run's: re-run tools/profile_workloads.sh"
     out.update(extra)
@@ -241,8 +249,11 @@ def main():
                     help="torch.distributed backend under torchrun (default nccl = RCCL; gloo lets several ranks share one GPU in tests)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--build", choices=["reference", "sah"], default="reference",
-                    help="mesh trees: the reference's median split (exact visiting order) or the opt-in SAH split")
+    ap.add_argument("--build", choices=["auto", "reference", "sah"], default="auto",
+                    help="mesh trees: both (the first render keeps the faster; the library's default), the reference's "
+                         "median split alone (its visiting order), or the surface-area split alone")
+    ap.add_argument("--no-reference-leg", action="store_true",
+                    help="skip the second timed run on the reference's trees in the reference's visiting order")
     ap.add_argument("--staged", action="store_true",
                     help="one launch per stage and depth (times the closest-hit kernel alone) instead of one kernel per batch")
     ap.add_argument("--force-dist", action="store_true",
@@ -286,74 +297,29 @@ def main():
         width, height = (int(v) for v in args.size.lower().split("x"))
 
     ctx = rt.Context(local) if per_process else rt.Context(devices=devices)
-    rt.set_default_build(rt.BUILD_SAH if args.build == "sah" else rt.BUILD_REFERENCE)
-    t0 = time.time()
-    if grouped and world > 1 and kind == "soup":
-        # one process per GPU: rank 0 flattens the scene and leaves it in the binary scene cache, the
-        # other ranks load it instead of building the same trees again on the same host cores
-        import tempfile
-        cache = os.environ.get("RT_SCENE_CACHE") or os.path.join(tempfile.gettempdir(), "rt_scene_cache")
-        os.makedirs(cache, exist_ok=True)
-        rt.set_default_cache_dir(cache)
-        if rank != 0:
-            dist.barrier()
-        wld = make_world(ctx, kind)
-        if rank == 0:
-            dist.barrier()
-        rt.set_default_cache_dir(None)
-    else:
-        wld = make_world(ctx, kind)
-    build_s = time.time() - t0
-    if args.wide_build == "device":
-        wld.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
-    wld.scene.set_traversal({"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE,
-                             "sweep": rt.TRAVERSAL_SWEEP, "ordered": rt.TRAVERSAL_ORDERED,
-                             "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}[args.traversal])
-    cam = wld.camera(width, height)
     accum = torch.zeros(height * width * 3, dtype=torch.float32, device=dev)
+    modes = {"auto": rt.TRAVERSAL_AUTO, "per_lane": rt.TRAVERSAL_PER_LANE, "sweep": rt.TRAVERSAL_SWEEP,
+             "ordered": rt.TRAVERSAL_ORDERED, "octant": rt.TRAVERSAL_OCTANT, "wide": rt.TRAVERSAL_WIDE}
 
-    def job(flags, samples=None, n_spp=None):
-        return wld.params(width, height, n_spp or spp, depth, samples=samples, flags=flags, max_paths=args.max_paths)
-
-    def share(p):
-        """this process's part of job p"""
-        if args.emulate:
-            er, en = (int(v) for v in args.emulate.split("/"))
-            return rt.partition_params(p, en, er)
-        return rt.partition_params(p, world, rank) if per_process else p
-
-    def render(p):
-        if per_process or args.emulate:
-            return wld.scene.render_device(cam, share(p), accum.data_ptr())
-        return wld.scene.render_multi_device(cam, p, accum.data_ptr())      # every GPU's share + the reduce
-
-    def step(flags):
-        accum.zero_()
-        torch.cuda.current_stream().synchronize()          # the renderer runs on its own streams
-        st = render(job(flags))                            # returns after the streams have drained
-        if per_process:
-            D.reduce_to_root(accum)
-        return st
-
-    if grouped:
-        D.reduce_to_root(accum)                            # builds the communicator outside the timed region
-        torch.cuda.synchronize()
-
-    # per-ray visit counts for the roofline: a counting pass over a few samples (not timed)
-    accum.zero_()
-    torch.cuda.synchronize()
-    cst = render(job(rt.RENDER_COUNT_VISITS, samples=(0, min(spp, 4))))
-    if grouped:
-        c = torch.tensor([float(cst[k]) for k in ("box_tests", "tri_tests", "sph_tests", "rays_traced")], dtype=torch.float64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        cst = dict(zip(("box_tests", "tri_tests", "sph_tests", "rays_traced"), c.tolist()))
-    n_box = cst["box_tests"] / max(cst["rays_traced"], 1)
-    n_tri = cst["tri_tests"] / max(cst["rays_traced"], 1)
-    n_sph = cst["sph_tests"] / max(cst["rays_traced"], 1)
-
-    timed_flags = rt.RENDER_PROFILE | (rt.RENDER_STAGED if args.staged else 0)
-    for _ in range(args.warmup):
-        step(timed_flags)
+    def build_world(build):
+        rt.set_default_build({"auto": rt.BUILD_AUTO, "reference": rt.BUILD_REFERENCE, "sah": rt.BUILD_SAH}[build])
+        t0 = time.time()
+        if grouped and world > 1 and kind == "soup":
+            # one process per GPU: rank 0 flattens the scene and leaves it in the binary scene cache, the
+            # other ranks load it instead of building the same trees again on the same host cores
+            import tempfile
+            cache = os.environ.get("RT_SCENE_CACHE") or os.path.join(tempfile.gettempdir(), "rt_scene_cache")
+            os.makedirs(cache, exist_ok=True)
+            rt.set_default_cache_dir(cache)
+            if rank != 0:
+                dist.barrier()
+            w = make_world(ctx, kind)
+            if rank == 0:
+                dist.barrier()
+            rt.set_default_cache_dir(None)
+        else:
+            w = make_world(ctx, kind)
+        return w, time.time() - t0
 
     def barrier():
         torch.cuda.synchronize()
@@ -361,56 +327,137 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    rays = paths = 0
-    ms_trace = ms_shade = ms_reduce = 0.0
-    launches = 0
-    form = 0
-    for _ in range(args.steps):
-        st = step(timed_flags)
-        rays += st["rays_traced"]
-        paths += st["paths"]
-        ms_trace += st["ms_trace"]
-        ms_shade += st["ms_shade"]
-        ms_reduce += st["ms_reduce"]
-        launches += st["trace_launches"]
-        form = st["kernel_form"]
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def measure(wld, traversal, steps, warmup, count_visits=True):
+        """W warm-up steps, then exactly K timed steps between barriers; the max over ranks of the elapsed
+        time, the sums of rays and paths, and what rank 0's (or the one process's) library calls reported."""
+        wld.scene.set_traversal(modes[traversal])
+        cam = wld.camera(width, height)
 
-    stats = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=dev)
-    mx = stats.clone()
-    sm = stats.clone()
+        def job(flags, samples=None, n_spp=None):
+            return wld.params(width, height, n_spp or spp, depth, samples=samples, flags=flags, max_paths=args.max_paths)
+
+        def share(p):
+            """this process's part of job p"""
+            if args.emulate:
+                er, en = (int(v) for v in args.emulate.split("/"))
+                return rt.partition_params(p, en, er)
+            return rt.partition_params(p, world, rank) if per_process else p
+
+        def render(p):
+            if per_process or args.emulate:
+                return wld.scene.render_device(cam, share(p), accum.data_ptr())
+            return wld.scene.render_multi_device(cam, p, accum.data_ptr())      # every GPU's share + the reduce
+
+        def step(flags):
+            accum.zero_()
+            torch.cuda.current_stream().synchronize()          # the renderer runs on its own streams
+            st = render(job(flags))                            # returns after the streams have drained
+            if per_process:
+                D.reduce_to_root(accum)
+            return st
+
+        timed_flags = rt.RENDER_PROFILE | (rt.RENDER_STAGED if args.staged else 0)
+        for _ in range(warmup):                                # (the first render of a scene also picks its kernel form)
+            step(timed_flags)
+        r = {"job": job, "render": render, "cam": cam}
+        if count_visits:
+            # per-ray visit counts for the roofline: a counting pass over a few samples (not timed), on the
+            # tree and in the form the warm-up left the scene in
+            if not warmup:
+                step(0)
+            accum.zero_()
+            torch.cuda.synchronize()
+            cst = render(job(rt.RENDER_COUNT_VISITS, samples=(0, min(spp, 4))))
+            if grouped:
+                c = torch.tensor([float(cst[k]) for k in ("box_tests", "tri_tests", "sph_tests", "rays_traced")], dtype=torch.float64, device=dev)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                cst = dict(zip(("box_tests", "tri_tests", "sph_tests", "rays_traced"), c.tolist()))
+            for k, name in (("box_tests", "n_box"), ("tri_tests", "n_tri"), ("sph_tests", "n_sph")):
+                r[name] = cst[k] / max(cst["rays_traced"], 1)
+        barrier()
+        t0 = time.perf_counter()
+        acc = {k: 0.0 for k in ("rays_traced", "paths", "ms_trace", "ms_shade", "ms_reduce", "trace_launches", "ms_kernel_span",
+                                "ms_render", "ms_render_min")}
+        clocks = []
+        st = None
+        for _ in range(steps):
+            st = step(timed_flags)
+            for k in acc:
+                acc[k] += st[k]
+            if st["shader_clock_ghz"] > 0:
+                clocks.append(st["shader_clock_ghz"])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stats = torch.tensor([elapsed, acc["rays_traced"], acc["paths"]], dtype=torch.float64, device=dev)
+        mx, sm = stats.clone(), stats.clone()
+        if grouped:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        r.update(acc)
+        r.update({"elapsed_max": float(mx[0]), "total_rays": float(sm[1]), "total_paths": float(sm[2]), "last": st,
+                  "clock_ghz": sum(clocks) / len(clocks) if clocks else None, "steps": steps,
+                  "mean": accum.view(height, width, 3).mean().item() / spp, "accum_sum": float(accum.double().sum().item())})
+        return r
+
     if grouped:
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-    elapsed_max = float(mx[0])
-    total_rays, total_paths = float(sm[1]), float(sm[2])
+        D.reduce_to_root(accum)                                # builds the communicator outside the timed region
+        torch.cuda.synchronize()
+    wld, build_s = build_world(args.build)
+    if args.wide_build == "device":
+        wld.scene.set_wide_build(rt.WIDE_BUILD_DEVICE)
+    m = measure(wld, args.traversal, args.steps, args.warmup)
+    # The same job once more on the reference's trees in the reference's visiting order (PER_LANE / SWEEP,
+    # whichever the library picks among those two): the strict form beside the chosen one.
+    ref = None
+    chosen_is_strict = (m["last"]["tree"] == 0 and rt.FORM_NAMES[m["last"]["kernel_form"]] in
+                        ("sweep", "walk", "walk_lds", "walk_refill", "walk_lds_refill"))
+    if not args.no_reference_leg and not chosen_is_strict and not args.staged and not args.emulate:
+        ref_world, _ = build_world("reference")
+        rm = measure(ref_world, "auto", args.steps, max(args.warmup, 1), count_visits=False)
+        ref = {"value": round(rm["total_rays"] / rm["elapsed_max"] / 1e6, 2), "unit": "Mrays/s",
+               "ms_per_step": round(rm["elapsed_max"] / args.steps * 1e3, 3),
+               "build": "reference", "kernel_form": rt.FORM_NAMES[rm["last"]["kernel_form"]],
+               "rays_per_step": int(rm["total_rays"] / args.steps), "accum_sum": rm["accum_sum"],
+               "note": "the reference's trees walked in the reference's visiting order: hits exact by construction"}
+        ref_world.close()
+    elif chosen_is_strict:
+        ref = {"note": "the timed run itself is a reference-order form on the reference's trees"}
 
     if rank == 0:
-        mean = accum.view(height, width, 3).mean().item() / spp
+        st = m["last"]
+        n_box, n_tri, n_sph = m["n_box"], m["n_tri"], m["n_sph"]
+        rays, paths, launches, ms_trace = m["rays_traced"], m["paths"], m["trace_launches"], m["ms_trace"]
+        elapsed_max, total_rays, total_paths = m["elapsed_max"], m["total_rays"], m["total_paths"]
         value = total_rays / elapsed_max / 1e6
-        bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph, 80.0 if args.traversal == "wide" else 32.0)
+        form_name = rt.FORM_NAMES[st["kernel_form"]] if st["kernel_form"] < len(rt.FORM_NAMES) else str(st["kernel_form"])
+        tree_name = rt.TREE_NAMES[st["tree"]]
+        is_wide = form_name.startswith("wide")
+        bytes_per_ray = trace_bytes_per_ray(n_box, n_tri, n_sph, 80.0 if is_wide else 32.0)
         # the dominant kernel on one GPU (rank 0's, or the slowest GPU's of a one-process job):
-        # algorithmic bytes of its launches / their summed duration.  Staged: the closest-hit kernel
-        # alone.  Default: the per-batch kernel, which also holds raygen and shade, so their stream
-        # bytes count too (shaded rays >= rays - paths: every ray either ends its path or is shaded).
+        # algorithmic bytes of its launches.  Staged: the closest-hit kernel alone.  Default: the
+        # per-batch kernel, which also holds raygen and shade, so their stream bytes count too
+        # (shaded rays >= rays - paths: every ray either ends its path or is shaded).
         n_here = 1 if per_process else world               # GPUs whose rays and launches `rays`, `launches` hold
         rays_gpu, paths_gpu, launches_gpu = rays / n_here, paths / n_here, launches / n_here
         algo_bytes = bytes_per_ray * rays_gpu
         if not args.staged:
             algo_bytes += SHADE_BYTES_PER_RAY * max(rays_gpu - paths_gpu, 0) + RAYGEN_BYTES_PER_PATH * paths_gpu
-        algo_gbs = algo_bytes / (ms_trace * 1e-3) / 1e9 if ms_trace > 0 else None
-        form_name = rt.FORM_NAMES[form] if form < len(rt.FORM_NAMES) else str(form)
+        # The pipelines' kernels overlap, so the algorithmic rate is taken over the wall time of the timed
+        # steps (what the chip delivered), not over the kernels' summed durations.
+        algo_gbs = algo_bytes / elapsed_max / 1e9
+        span = m["ms_kernel_span"]
         extra = {
             "kernel": "k_trace (closest hit)" if args.staged else
                       "k_path (raygen + closest hit and shade per depth, one launch per batch)",
             "rays_per_launch": int(rays_gpu / max(launches_gpu, 1)),
             "algorithmic_bytes_per_launch": int(algo_bytes / max(launches_gpu, 1)),
             "avg_launch_ms": round(ms_trace / max(launches_gpu, 1), 4), "launches": int(launches_gpu),
-            "trace_ms_per_step": round(ms_trace / args.steps, 2),
-            "shade_ms_per_step": round(ms_shade / args.steps, 2),
+            "launch_timing": "HIP events around every launch on the stream it runs on; launches of the pipelines overlap "
+                             "(launches_in_flight), so summed durations exceed the step",
+            "launches_in_flight": round(ms_trace / span, 2) if span > 0 else None,
+            "kernel_span_ms_per_step": round(span / args.steps, 3),
+            "summed_launch_ms_per_step": round(ms_trace / args.steps, 2),
+            "shade_ms_per_step": round(m["ms_shade"] / args.steps, 2),
         }
         headline = not (args.spp or args.size or args.emulate or args.staged)
         out = {
@@ -420,27 +467,38 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {kind} {width}x{height}, {spp} spp, max depth {depth}",
-                       "build": args.build, "traversal": args.traversal, "kernel_form": form_name,
+                       "build": args.build, "traversal": args.traversal, "tree": tree_name, "kernel_form": form_name,
                        **({"wide_build": args.wide_build} if args.traversal == "wide" else {}),
                        "parallelism": (f"{world} processes x 1 GPU, torch.distributed reduce" if per_process else
                                        f"1 process x {world} GPU(s), rt_render_multi (RCCL reduce in the library)"),
                        "partition": "rt_partition: interleaved 64-row bands x sample ranges",
                        "rays_per_step": int(total_rays / args.steps), "paths_per_step": int(total_paths / args.steps),
-                       "mean_radiance": round(mean, 5), "scene_build_s": round(build_s, 3),
-                       "reduce_ms_per_step": round(ms_reduce / args.steps, 3),
-                       "accum_sum": float(accum.double().sum().item())},
-            # (the opt-in walks have counter records of their own, keyed <workload>/<build>/<traversal>)
-            "roofline": roofline(args.workload if headline or args.spp else None,
-                                 args.build + (f"/{args.traversal}" if args.traversal in ("wide", "ordered", "octant") else ""),
+                       "mean_radiance": round(m["mean"], 5), "scene_build_s": round(build_s, 3),
+                       "reduce_ms_per_step": round(m["ms_reduce"] / args.steps, 3),
+                       "accum_sum": m["accum_sum"]},
+            "reference_order": ref,
+            "roofline": roofline(args.workload if headline or args.spp else None, f"{tree_name}/{form_name}",
                                  form_name, total_rays / elapsed_max,
                                  world, algo_gbs, bytes_per_ray,
-                                 {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)}, extra),
+                                 {"box": round(n_box, 2), "tri": round(n_tri, 2), "sph": round(n_sph, 2)}, extra,
+                                 clock_ghz=m["clock_ghz"]),
         }
+        if not per_process:
+            # what the library reports about its GPUs and its reduce (the last timed step)
+            n_show = min(world, 16)
+            out["multi_gpu"] = {
+                "rccl_ranks": st["rccl_ranks"], "reduce": "rccl" if st["reduce_mode"] == rt.REDUCE_RCCL else "ordered (copied to the root, added in rank order)",
+                "reduce_ms": round(st["ms_reduce"], 3),
+                "device_ms_render": [round(v, 3) for v in st["device_ms_render"][:n_show]],
+                "ms_render_min": round(st["ms_render_min"], 3), "ms_render_max": round(st["ms_render"], 3),
+                "slowest_device": st["slowest_device"],
+                "device_kernel_form": [rt.FORM_NAMES[f] for f in st["device_form"][:n_show]],
+                "device_tree": [rt.TREE_NAMES[t] for t in st["device_tree"][:n_show]]}
         if world == 1 and not args.no_cpu:
             def gpu_render(n_spp):
                 accum.zero_()
                 torch.cuda.synchronize()
-                wld.scene.render_device(cam, job(0, n_spp=n_spp), accum.data_ptr())
+                wld.scene.render_device(m["cam"], m["job"](0, n_spp=n_spp), accum.data_ptr())
                 return accum.view(height, width, 3).cpu().numpy()
             base = cpu_baseline(kind, width, height, depth, args.cpu_seconds, gpu_render)
             if base:
