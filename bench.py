@@ -360,20 +360,6 @@ def main():
         for _ in range(warmup):                                # (the first render of a scene also picks its kernel form)
             step(timed_flags)
         r = {"job": job, "render": render, "cam": cam}
-        if count_visits:
-            # per-ray visit counts for the roofline: a counting pass over a few samples (not timed), on the
-            # tree and in the form the warm-up left the scene in
-            if not warmup:
-                step(0)
-            accum.zero_()
-            torch.cuda.synchronize()
-            cst = render(job(rt.RENDER_COUNT_VISITS, samples=(0, min(spp, 4))))
-            if grouped:
-                c = torch.tensor([float(cst[k]) for k in ("box_tests", "tri_tests", "sph_tests", "rays_traced")], dtype=torch.float64, device=dev)
-                dist.all_reduce(c, op=dist.ReduceOp.SUM)
-                cst = dict(zip(("box_tests", "tri_tests", "sph_tests", "rays_traced"), c.tolist()))
-            for k, name in (("box_tests", "n_box"), ("tri_tests", "n_tri"), ("sph_tests", "n_sph")):
-                r[name] = cst[k] / max(cst["rays_traced"], 1)
         barrier()
         t0 = time.perf_counter()
         acc = {k: 0.0 for k in ("rays_traced", "paths", "ms_trace", "ms_shade", "ms_reduce", "trace_launches", "ms_kernel_span",
@@ -393,6 +379,20 @@ def main():
         if grouped:
             dist.all_reduce(mx, op=dist.ReduceOp.MAX)
             dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        if count_visits:
+            # per-ray visit counts for the roofline: a counting pass over a few samples (not timed), on the
+            # tree and in the form the timed steps ran
+            accum_keep = accum.clone()
+            accum.zero_()
+            torch.cuda.synchronize()
+            cst = render(job(rt.RENDER_COUNT_VISITS, samples=(0, min(spp, 4))))
+            if grouped:
+                c = torch.tensor([float(cst[k]) for k in ("box_tests", "tri_tests", "sph_tests", "rays_traced")], dtype=torch.float64, device=dev)
+                dist.all_reduce(c, op=dist.ReduceOp.SUM)
+                cst = dict(zip(("box_tests", "tri_tests", "sph_tests", "rays_traced"), c.tolist()))
+            for k, name in (("box_tests", "n_box"), ("tri_tests", "n_tri"), ("sph_tests", "n_sph")):
+                r[name] = cst[k] / max(cst["rays_traced"], 1)
+            accum.copy_(accum_keep)
         r.update(acc)
         r.update({"elapsed_max": float(mx[0]), "total_rays": float(sm[1]), "total_paths": float(sm[2]), "last": st,
                   "clock_ghz": sum(clocks) / len(clocks) if clocks else None, "steps": steps,

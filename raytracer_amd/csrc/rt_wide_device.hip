@@ -11,15 +11,21 @@
 //      of equal next Morton digit -- the digit IS the child slot, because bit k of a slot means "the
 //      positive side along axis k" in the walk's ordering rule -- digits on which the whole run
 //      agrees are skipped, runs that agree on all thirty bits are cut into equal parts, a run of
-//      one key is a primitive child.  Node slots come in blocks of eight from a counter;
+//      one key is a primitive child.  The node children of a node take consecutive slots from a
+//      counter, from its lowest to its highest occupied child slot (child slot s lives at
+//      child_base + s, so only the empty slots between two occupied ones cost memory); this pass
+//      writes a four-word head per run, not the nodes, so the node array can be allocated at its
+//      exact size afterwards;
 //   4. bottom up, one launch per level: a node's children's boxes (a primitive's padded box, a
 //      node's union) are quantised to the node's grid exactly as rt_wide.cpp does, one step of
-//      slack on every side.
+//      slack on every side, and the node is written.
 //
 // The result has the format of WideScene and is walked by the same kernels.  The trees are an
 // octree in disguise: as good as a surface-area tree where primitives are small and evenly spread
 // (the triangle soup), worse where sizes are mixed; the build takes milliseconds instead of seconds.
-// Objects of a list at the root are not marked (word 7 of the nodes stays 0).
+// Primitives the reference tests without a box test before them (the objects of a list at the
+// root: the primitive entries that no box entry spans) are found with a prefix maximum over the
+// box entries' skip links and marked in word 7 of every node above them, as rt_wide.cpp does.
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -37,6 +43,7 @@ namespace {
 constexpr uint32_t WB = 256;
 
 struct Counters { uint32_t n_prims, n_next, slots, prim_records, overflow, pad[3]; };
+constexpr uint32_t BOXLESS = 1u << 31;         // flag beside an entry index (entry indices stay below 2^30)
 struct Run { uint32_t b, e, slot; int32_t shift; };     // keys [b, e) form the node at `slot`; next digit at bit 32 + shift
 
 __device__ __forceinline__ uint32_t ordered(float f) {           // an unsigned whose order is the floats'
@@ -66,18 +73,42 @@ __device__ __forceinline__ void prim_box(const float4& a, const float4& b, const
     for (int k = 0; k < 3; k++) { lo[k] -= pad; hi[k] += pad; }
 }
 
-// primitive entries -> compact list; bounds of the box centres (as ordered unsigneds: [0..2] min, [3..5] max)
+// reach[e] = the entry behind the subtree of box entry e (0 for other entries): after an exclusive
+// prefix maximum, a primitive entry e with reach[e] <= e lies under no box
 __global__ void __launch_bounds__(WB)
-k_collect(const float4* __restrict__ ent, uint32_t n_entries, uint32_t* __restrict__ prim_entry, Counters* cnt,
-          uint32_t* __restrict__ bounds) {
+k_reach(const float4* __restrict__ ent, uint32_t n_entries, uint32_t* __restrict__ reach) {
+    const uint32_t e = blockIdx.x * WB + threadIdx.x;
+    if (e >= n_entries) return;
+    const uint32_t w = __float_as_uint(ent[4 * (size_t)e].w);
+    reach[e] = (w >> TAG_SHIFT) == TAG_BOX ? (w & SKIP_MASK) : 0u;
+}
+
+// primitive entries -> compact list (entry index | BOXLESS); bounds of the box centres (as ordered
+// unsigneds: [0..2] min, [3..5] max).  The list is numbered per wave: one ballot, one atomic of the
+// wave's count, the lanes' places by prefix (one atomic per PRIMITIVE on the single counter took 18 of
+// the build's 22 ms of kernel time on 10 M triangles).  `cover` is null when no primitive can be box-less.
+__global__ void __launch_bounds__(WB)
+k_collect(const float4* __restrict__ ent, uint32_t n_entries, const uint32_t* __restrict__ cover,
+          uint32_t* __restrict__ prim_entry, Counters* cnt, uint32_t* __restrict__ bounds) {
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-    for (uint32_t e = blockIdx.x * WB + threadIdx.x; e < n_entries; e += gridDim.x * WB) {
-        const float4 a = ent[4 * (size_t)e];
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = blockIdx.x * WB; base < n_entries; base += gridDim.x * WB) {     // (wave-uniform trip count)
+        const uint32_t e = base + threadIdx.x;
+        float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (e < n_entries) a = ent[4 * (size_t)e];
         const uint32_t tag = __float_as_uint(a.w) >> TAG_SHIFT;
-        if (tag != TAG_TRI && tag != TAG_SPH) continue;
+        const bool is_prim = e < n_entries && (tag == TAG_TRI || tag == TAG_SPH);
+        const unsigned long long m = __ballot(is_prim);
+        if (m == 0ull) continue;
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&cnt->n_prims, (uint32_t)__popcll(m));
+        first = (uint32_t)__shfl((int)first, 0);
+        if (!is_prim) continue;
+        const uint32_t at = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const bool boxless = cover != nullptr && cover[e] <= e;
+        prim_entry[at] = e | (boxless ? BOXLESS : 0u);
         float lo[3], hi[3];
         prim_box(a, ent[4 * (size_t)e + 1], ent[4 * (size_t)e + 2], lo, hi);
-        prim_entry[atomicAdd(&cnt->n_prims, 1u)] = e;
         for (int k = 0; k < 3; k++) {
             const uint32_t c = ordered(0.5f * lo[k] + 0.5f * hi[k]);
             mn[k] = min(mn[k], c);
@@ -90,7 +121,7 @@ k_collect(const float4* __restrict__ ent, uint32_t n_entries, uint32_t* __restri
             mn[k] = min(mn[k], (uint32_t)__shfl_xor((int)mn[k], off));
             mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], off));
         }
-        if ((threadIdx.x & 63u) == 0) {
+        if (lane == 0) {
             atomicMin(&bounds[k], mn[k]);
             atomicMax(&bounds[3 + k], mx[k]);
         }
@@ -110,7 +141,7 @@ k_keys(const float4* __restrict__ ent, const uint32_t* __restrict__ prim_entry, 
        unsigned long long* __restrict__ keys) {
     const uint32_t i = blockIdx.x * WB + threadIdx.x;
     if (i >= n) return;
-    const uint32_t e = prim_entry[i];
+    const uint32_t ef = prim_entry[i], e = ef & ~BOXLESS;
     float lo[3], hi[3];
     prim_box(ent[4 * (size_t)e], ent[4 * (size_t)e + 1], ent[4 * (size_t)e + 2], lo, hi);
     uint32_t q[3];
@@ -122,15 +153,17 @@ k_keys(const float4* __restrict__ ent, const uint32_t* __restrict__ prim_entry, 
         q[k] = (uint32_t)fminf(fmaxf(t, 0.0f), 1023.0f);
     }
     const uint32_t code = spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2;
-    keys[i] = (unsigned long long)code << 32 | e;
+    keys[i] = (unsigned long long)code << 32 | ef;             // (the flag travels in the key's low word)
 }
 
 __device__ __forceinline__ uint32_t digit_of(unsigned long long key, int shift) { return (uint32_t)(key >> (32 + shift)) & 7u; }
 
-// one level, top down: every run becomes a node and names its children
+// one level, top down: every run becomes a node and names its children.  heads[run] = (mask of
+// the child slots that hold nodes, node slot of child slot 0, first primitive record, mask of the
+// child slots that hold primitives); bit 8 + s of the first word: primitive child s is box-less.
 __global__ void __launch_bounds__(WB)
 k_split(const unsigned long long* __restrict__ keys, const float4* __restrict__ ent, Run* __restrict__ runs, uint32_t off_in,
-        uint32_t n_in, uint32_t off_out, Counters* cnt, uint32_t* __restrict__ nodes, uint32_t stride, uint32_t slot_capacity,
+        uint32_t n_in, uint32_t off_out, Counters* cnt, uint4* __restrict__ heads, uint32_t slot_capacity,
         float4* __restrict__ prims) {
     const uint32_t i = blockIdx.x * WB + threadIdx.x;
     if (i >= n_in) return;
@@ -161,14 +194,18 @@ k_split(const unsigned long long* __restrict__ keys, const float4* __restrict__ 
     }
     uint32_t cbase = 0;
     if (imask) {
-        cbase = atomicAdd(&cnt->slots, 8u);
-        if (cbase + 8u > slot_capacity) { cnt->overflow = 1u; return; }
+        // the node children's slots: from the lowest to the highest occupied child slot
+        const uint32_t low = (uint32_t)__ffs((int)imask) - 1u, span = 32u - (uint32_t)__clz((int)imask) - low;
+        const uint32_t first = atomicAdd(&cnt->slots, span);
+        if (first + span > slot_capacity) { cnt->overflow = 1u; return; }
+        cbase = first - low;                   // (first >= 8 > low)
     }
     const uint32_t pbase = atomicAdd(&cnt->prim_records, (uint32_t)__popc(lmask));
-    uint32_t rank = 0;
+    uint32_t rank = 0, boxless = 0;
     for (uint32_t k = 0; k < 8; k++) {
         if (!(lmask >> k & 1u)) continue;
-        const uint32_t e = (uint32_t)keys[cb[k]];
+        const uint32_t ef = (uint32_t)keys[cb[k]], e = ef & ~BOXLESS;
+        if (ef & BOXLESS) boxless |= 1u << k;
         float4* dst = prims + 4 * (size_t)(pbase + rank);
         dst[0] = ent[4 * (size_t)e]; dst[1] = ent[4 * (size_t)e + 1]; dst[2] = ent[4 * (size_t)e + 2];
         dst[3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -179,12 +216,7 @@ k_split(const unsigned long long* __restrict__ keys, const float4* __restrict__ 
         for (uint32_t k = 0; k < 8; k++)
             if (imask >> k & 1u) runs[at++] = Run{cb[k], cb[k + 1], cbase + k, shift - 3};
     }
-    uint32_t* w = nodes + (size_t)r.slot * stride;
-    w[3] = imask << 24;
-    w[4] = cbase;
-    w[5] = pbase;
-    w[6] = lmask;
-    w[7] = 0u;
+    heads[off_in + i] = make_uint4(imask | boxless << 8, cbase, pbase, lmask);
 }
 
 // grid of one axis of a node (WideBuilder::grid_for): step 2^(e - 127) and an origin two steps below lo
@@ -210,13 +242,20 @@ __device__ __forceinline__ bool grid_for(float lo, float hi, float& origin, uint
 
 // one level, bottom up: boxes of the children, the node's grid, the planes
 __global__ void __launch_bounds__(WB)
-k_refit(const Run* __restrict__ runs, uint32_t off, uint32_t n, uint32_t* __restrict__ nodes, uint32_t stride,
-        const float4* __restrict__ prims, float* __restrict__ node_box, Counters* cnt) {
+k_refit(const Run* __restrict__ runs, const uint4* __restrict__ heads, uint32_t off, uint32_t n, uint32_t* __restrict__ nodes,
+        uint32_t stride, const float4* __restrict__ prims, float* __restrict__ node_box, uint8_t* __restrict__ node_boxless,
+        Counters* cnt) {
     const uint32_t i = blockIdx.x * WB + threadIdx.x;
     if (i >= n) return;
     const uint32_t slot = runs[off + i].slot;
     uint32_t* w = nodes + (size_t)slot * stride;
-    const uint32_t imask = w[3] >> 24, lmask = w[6], cbase = w[4], pbase = w[5];
+    const uint4 head = heads[off + i];
+    const uint32_t imask = head.x & 0xFFu, lmask = head.w, cbase = head.y, pbase = head.z;
+    // children the reference reaches without a box test: box-less primitives, and nodes that hold one
+    uint32_t amask = (head.x >> 8) & lmask;
+    for (uint32_t s = 0; s < 8; s++)
+        if ((imask >> s & 1u) && node_boxless[cbase + s]) amask |= 1u << s;
+    node_boxless[slot] = amask ? 1 : 0;
     float clo[8][3], chi[8][3];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     uint32_t rank = 0;
@@ -253,6 +292,7 @@ k_refit(const Run* __restrict__ runs, uint32_t off, uint32_t n, uint32_t* __rest
     }
     w[0] = __float_as_uint(origin[0]); w[1] = __float_as_uint(origin[1]); w[2] = __float_as_uint(origin[2]);
     w[3] = e[0] | e[1] << 8 | e[2] << 16 | imask << 24;
+    w[4] = cbase; w[5] = pbase; w[6] = lmask; w[7] = amask;
     for (int p = 0; p < 12; p++) w[8 + p] = planes[p];
 }
 
@@ -286,48 +326,61 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
     HIP_OK(tmp.get((void**)&bounds, 6 * sizeof(uint32_t)));
     HIP_OK(tmp.get((void**)&prim_entry, (size_t)n_entries * 4));
     HIP_OK(hipMemsetAsync(cnt, 0, sizeof(Counters), st));
+    uint32_t first_word = 0;
     {
         const uint32_t init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         HIP_OK(hipMemcpyAsync(bounds, init, sizeof(init), hipMemcpyHostToDevice, st));
+        if (n_entries) HIP_OK(hipMemcpyAsync(&first_word, (const char*)d_entries + 12, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
     auto grid = [](size_t n) { return (uint32_t)std::min<size_t>(std::max<size_t>((n + WB - 1) / WB, 1), 65536); };
-    if (n_entries) hipLaunchKernelGGL(k_collect, dim3(grid(n_entries)), dim3(WB), 0, st, ent, n_entries, prim_entry, cnt, bounds);
+    // Box-less primitives exist unless one box spans every entry (a Bvh or a mesh at the root): only
+    // then is the prefix maximum over the boxes' skip links needed.
+    uint32_t* cover = nullptr;
+    const bool one_box_spans_all = n_entries && (first_word >> TAG_SHIFT) == TAG_BOX && (first_word & SKIP_MASK) == n_entries;
+    if (n_entries && !one_box_spans_all) {
+        uint32_t* reach = nullptr;
+        HIP_OK(tmp.get((void**)&reach, (size_t)n_entries * 4));
+        HIP_OK(tmp.get((void**)&cover, (size_t)n_entries * 4));
+        hipLaunchKernelGGL(k_reach, dim3((n_entries + WB - 1) / WB), dim3(WB), 0, st, ent, n_entries, reach);
+        size_t scan_bytes = 0;
+        HIP_OK(hipcub::DeviceScan::ExclusiveScan(nullptr, scan_bytes, reach, cover, hipcub::Max(), 0u, (int)n_entries, st));
+        void* scan_tmp = nullptr;
+        HIP_OK(tmp.get(&scan_tmp, scan_bytes));
+        HIP_OK(hipcub::DeviceScan::ExclusiveScan(scan_tmp, scan_bytes, reach, cover, hipcub::Max(), 0u, (int)n_entries, st));
+    }
+    if (n_entries) hipLaunchKernelGGL(k_collect, dim3(grid(n_entries)), dim3(WB), 0, st, ent, n_entries, (const uint32_t*)cover, prim_entry, cnt, bounds);
     Counters h{};
     HIP_OK(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     const uint32_t n = h.n_prims;
     if (n >= (1u << 30)) { error = "too many primitives"; return -1; }
 
-    // the tree's arrays: node slots in blocks of eight (the root alone in slot 0), one record per primitive
+    // the tree's arrays: one record per primitive now, the nodes once their number is known
     const uint32_t stride = (size_t)n * 40 > WIDE_PACKED_MAX_BYTES ? WIDE_LINE_WORDS : WIDE_NODE_WORDS;
-    // (a node with a node among its children takes a block of eight slots, and there are fewer nodes than
-    // primitives; the walk's stack words hold 24-bit slot numbers)
-    const size_t slot_capacity = std::min<size_t>((size_t)1 << 24, 8 + 8 * (size_t)n);
+    // (the walk's stack words hold 24-bit slot numbers)
+    const size_t slot_capacity = (size_t)1 << 24;
     void* d_nodes = nullptr;
     void* d_prims = nullptr;
-    if (hipMalloc(&d_nodes, slot_capacity * stride * 4) != hipSuccess) { error = "out of device memory for the wide tree's nodes"; return -1; }
     if (hipMalloc(&d_prims, std::max<size_t>((size_t)n * WIDE_PRIM_FLOATS * 4, 64)) != hipSuccess) {
-        (void)hipFree(d_nodes);
         error = "out of device memory for the wide tree's primitive records";
         return -1;
     }
     struct Owned {                             // released unless the build succeeds
         void *a, *b;
         bool keep = false;
-        ~Owned() { if (!keep) { (void)hipFree(a); (void)hipFree(b); } }
-    } owned{d_nodes, d_prims};
-    HIP_OK(hipMemsetAsync(d_nodes, 0, slot_capacity * stride * 4, st));
+        ~Owned() { if (!keep) { if (a) (void)hipFree(a); if (b) (void)hipFree(b); } }
+    } owned{nullptr, d_prims};
 
-    uint32_t depth = 1;
+    uint32_t depth = 1, slots = 1;
     if (n > 0) {
         unsigned long long *keys_in = nullptr, *keys = nullptr;
         Run* runs = nullptr;
-        float* node_box = nullptr;
+        uint4* heads = nullptr;
         HIP_OK(tmp.get((void**)&keys_in, (size_t)n * 8));
         HIP_OK(tmp.get((void**)&keys, (size_t)n * 8));
         HIP_OK(tmp.get((void**)&runs, ((size_t)n + 1) * sizeof(Run)));
-        HIP_OK(tmp.get((void**)&node_box, slot_capacity * 6 * sizeof(float)));
+        HIP_OK(tmp.get((void**)&heads, ((size_t)n + 1) * sizeof(uint4)));
         hipLaunchKernelGGL(k_keys, dim3((n + WB - 1) / WB), dim3(WB), 0, st, ent, prim_entry, n, bounds, keys_in);
         size_t sort_bytes = 0;
         HIP_OK(hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, keys_in, keys, (int)n, 0, 62, st));
@@ -339,13 +392,15 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
         std::vector<uint32_t> off{0u, 1u};
         const Run root{0u, n, 0u, 27};
         HIP_OK(hipMemcpyAsync(runs, &root, sizeof(root), hipMemcpyHostToDevice, st));
-        h.slots = 1u; h.n_next = 0u; h.prim_records = 0u; h.overflow = 0u;
+        // (slot 0 is the root; the counter starts at 8 so that child_base = first slot - lowest occupied
+        // child slot never falls below zero)
+        h.slots = 8u; h.n_next = 0u; h.prim_records = 0u; h.overflow = 0u;
         HIP_OK(hipMemcpyAsync(cnt, &h, sizeof(h), hipMemcpyHostToDevice, st));
         HIP_OK(hipStreamSynchronize(st));      // (root and h leave scope as values; keep it simple)
         for (;;) {
             const uint32_t level = (uint32_t)off.size() - 2, n_in = off[level + 1] - off[level];
             hipLaunchKernelGGL(k_split, dim3((n_in + WB - 1) / WB), dim3(WB), 0, st, keys, ent, runs, off[level], n_in,
-                               off[level + 1], cnt, (uint32_t*)d_nodes, stride, (uint32_t)slot_capacity, (float4*)d_prims);
+                               off[level + 1], cnt, heads, (uint32_t)slot_capacity, (float4*)d_prims);
             HIP_OK(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
             HIP_OK(hipStreamSynchronize(st));
             if (h.overflow) { error = "the device-built wide tree needs more than 2^24 node slots"; return -1; }
@@ -356,39 +411,39 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
             HIP_OK(hipMemsetAsync(&cnt->n_next, 0, 4, st));
         }
         depth = (uint32_t)off.size() - 1;
+        slots = h.slots;
         if (h.prim_records != n) { error = "internal error: wide tree lost primitives"; return -1; }
+        // the nodes, at their exact number
+        if (hipMalloc(&d_nodes, (size_t)slots * stride * 4) != hipSuccess) { error = "out of device memory for the wide tree's nodes"; return -1; }
+        owned.a = d_nodes;
+        HIP_OK(hipMemsetAsync(d_nodes, 0, (size_t)slots * stride * 4, st));
+        float* node_box = nullptr;
+        uint8_t* node_boxless = nullptr;
+        HIP_OK(tmp.get((void**)&node_box, (size_t)slots * 6 * sizeof(float)));
+        HIP_OK(tmp.get((void**)&node_boxless, (size_t)slots));
+        HIP_OK(hipMemsetAsync(node_boxless, 0, (size_t)slots, st));
         // bottom up
         for (uint32_t level = depth; level-- > 0;) {
             const uint32_t n_in = off[level + 1] - off[level];
-            hipLaunchKernelGGL(k_refit, dim3((n_in + WB - 1) / WB), dim3(WB), 0, st, runs, off[level], n_in, (uint32_t*)d_nodes,
-                               stride, (const float4*)d_prims, node_box, cnt);
+            hipLaunchKernelGGL(k_refit, dim3((n_in + WB - 1) / WB), dim3(WB), 0, st, runs, heads, off[level], n_in,
+                               (uint32_t*)d_nodes, stride, (const float4*)d_prims, node_box, node_boxless, cnt);
         }
         HIP_OK(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         if (h.overflow) { error = "wide tree: a box is not finite"; return -1; }
+    } else {
+        if (hipMalloc(&d_nodes, (size_t)stride * 4) != hipSuccess) { error = "out of device memory for the wide tree's nodes"; return -1; }
+        owned.a = d_nodes;
+        HIP_OK(hipMemsetAsync(d_nodes, 0, (size_t)stride * 4, st));
     }
     HIP_OK(hipStreamSynchronize(st));
     if (hipGetLastError() != hipSuccess) { error = "a kernel of the device-side wide build failed to launch"; return -1; }
-    // the node array was sized for the worst case: keep what is in use
-    const size_t used_bytes = (size_t)(n > 0 ? h.slots : 1u) * stride * 4;
-    if (used_bytes < slot_capacity * stride * 4 / 2) {
-        void* small = nullptr;
-        if (hipMalloc(&small, used_bytes) == hipSuccess) {
-            if (hipMemcpy(small, d_nodes, used_bytes, hipMemcpyDeviceToDevice) == hipSuccess) {
-                (void)hipFree(d_nodes);
-                d_nodes = small;
-                owned.a = small;
-            } else {
-                (void)hipFree(small);
-            }
-        }
-    }
     owned.keep = true;
     out.nodes = d_nodes;
     out.prims = d_prims;
-    out.nodes_bytes = used_bytes;
+    out.nodes_bytes = (size_t)slots * stride * 4;
     out.prims_bytes = std::max<size_t>((size_t)n * WIDE_PRIM_FLOATS * 4, 64);
-    out.n_slots = n > 0 ? h.slots : 1u;
+    out.n_slots = slots;
     out.n_prims = n;
     out.depth = depth;
     out.node_words = stride;

@@ -93,7 +93,9 @@ def main():
                 v["time_share"] = round(v.pop("kernel_seconds") / total_t, 3) if total_t else None
             stage_rows.append((wl, tree, form, stages))
         records[key] = {
-            "form": form, "tree": tree, "stages": stages, "rays_profiled": rays, "spp_profiled": j["config"]["workload"].split(", ")[1],
+            "form": form, "tree": tree, "stages": stages, "rays_profiled": rays,
+            # the library took this tree and form by itself (the plain run was an RT_BUILD_AUTO / RT_TRAVERSAL_AUTO one)
+            "picked_by_auto": plain["config"]["build"] == "auto" and plain["config"]["traversal"] == "auto", "spp_profiled": j["config"]["workload"].split(", ")[1],
             "hbm_bytes_per_ray": round(hbm_per_ray, 2),
             "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
             "valu_insts_per_ray": round(valu_per_ray, 2), "salu_insts_per_ray": round(sq["SQ_INSTS_SALU"] / rays, 2),
