@@ -660,12 +660,7 @@ static int apply_traversal(rt_scene* s, int mode) {
         }
     }
     if (s->dev.wide && !std::getenv("RT_REFILL")) s->dev.refill = 16;      // the wide walk refills idle lanes by default
-    if (s->dev.n_xforms != 0) {                // one form follows the transform markers: the plain walk from memory
-        s->dev.sweep = 0;
-        s->dev.refill = 0;
-        s->dev.lds_walk = 0;
-        s->auto_tuned = true;
-    }
+    if (s->dev.n_xforms != 0) s->dev.sweep = 0;   // the per-lane walks (from memory, out of LDS, refilled) follow the transform markers
     return RT_OK;
 }
 
@@ -1161,14 +1156,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             for (int which : {base, 1 - base}) {
                 const SceneTree& t = s->trees[which];
                 if (!t.present) continue;
-                if (t.n_entries <= SWEEP_MAX_ENTRIES) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
+                if (t.n_entries <= SWEEP_MAX_ENTRIES && s->dev.n_xforms == 0) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
                 if (t.lds_walk) forms.push_back(Form{which, 0u, pinned_refill ? s->env_refill : 0u, s->dev.prim_wait, 0u});
                 else if (pinned_refill) forms.push_back(Form{which, 0u, s->env_refill, s->dev.prim_wait, 0u});
                 else { forms.push_back(Form{which, 0u, 0u, wait_mem, 0u}); forms.push_back(Form{which, 0u, 16u, wait_refill, 0u}); }
             }
             // the wide walk over the surface-area trees, for scenes that are walked from memory
             if (s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && !s->trees[TREE_FAST].lds_walk &&
-                !std::getenv("RT_AUTO_NO_WIDE")) {
+                s->dev.n_xforms == 0 && !std::getenv("RT_AUTO_NO_WIDE")) {
                 const int was = s->cur;
                 bind_tree(s, TREE_FAST);
                 const int wrc = ensure_wide_tree(s);

@@ -225,20 +225,52 @@ __device__ __forceinline__ void fetch_entry(const float4* __restrict__ ent, uint
     if (RT_WALK_LOADS >= 3) e.c = ent[i + 2];
     if (RT_WALK_LOADS >= 4) e.d = ent[i + 3];
 }
+// glam's Mat4::transform_point3 (w = 1) / transform_vector3 (w = 0) on the four columns at m:
+// ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w in rounded f32 steps (no contraction here).
+__device__ __forceinline__ void xf_apply(const float4* __restrict__ m, float x, float y, float z, float w, float& ox,
+                                         float& oy, float& oz) {
+    const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
+    ox = c3.x * w + (c2.x * z + (c1.x * y + c0.x * x));
+    oy = c3.y * w + (c2.y * z + (c1.y * y + c0.y * x));
+    oz = c3.z * w + (c2.z * z + (c1.z * y + c0.z * x));
+}
+
+// The caller's ray of a lane that walks a scene with transformed meshes (XF forms).  The linked units of
+// such a scene carry an ENTER marker in front of a transformed mesh's tree and a LEAVE marker behind it
+// (rt_internal.hpp: END_CODE_*).  At ENTER the lane's ray goes to the mesh's local space, as Mesh::hit
+// does before it descends (shape.rs:454: ray.transform(&self.inverse_transform)); t is the same
+// parameter in both spaces, so best_t carries over; at LEAVE the caller's ray is back.  Meshes are
+// leaves, so one saved ray is enough.
+struct WorldRay { float ox, oy, oz, dx, dy, dz; };
 // One trip of the per-lane walk for the whole wave: lanes at a box test it and move on; lanes at a
 // primitive run its routine once enough of them wait (or no lane stands at a box).  Returns false
 // when no lane has an entry left.  A lane without a further entry holds TAG_END in the tag word of
 // e.a, so "at a box" and "at a primitive" are single compares whose lane masks are the ballots.
-template <bool COUNT, bool TIE = false>
+template <bool COUNT, bool TIE = false, bool XF = false>
 __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32_t prim_wait, LaneRay& r, LaneEntry& e,
-                                          float t_min, Counts& cnt) {
+                                          float t_min, Counts& cnt, const float4* __restrict__ xforms = nullptr,
+                                          const WorldRay* world = nullptr) {
     const uint32_t tag = f2u(e.a.w) >> TAG_SHIFT;
     const bool at_box = tag == TAG_BOX;
     const bool at_prim = tag - TAG_TRI < 2u;           // TAG_TRI or TAG_SPH
     static_assert(TAG_TRI == 1 && TAG_SPH == 2 && TAG_END == 3, "tag order");
-    const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim);
-    if ((mb | mp) == 0ull) return false;
+    // (XF: a marker shares the tag of the end units and tells itself apart by its first word)
+    const bool at_marker = XF && tag == TAG_END && f2u(e.a.x) != END_CODE_END;
+    const unsigned long long mb = __ballot(at_box), mp = __ballot(at_prim), mm = XF ? __ballot(at_marker) : 0ull;
+    if ((mb | mp | mm) == 0ull) return false;
     RT_UTIL_TRIP(cnt);
+    if (XF && at_marker) {
+        if (f2u(e.a.x) == END_CODE_ENTER) {
+            const float4* inv = xforms + 8u * f2u(e.a.y) + 4u;
+            xf_apply(inv, world->ox, world->oy, world->oz, 1.0f, r.ox, r.oy, r.oz);     // camera.rs:137-142
+            xf_apply(inv, world->dx, world->dy, world->dz, 0.0f, r.dx, r.dy, r.dz);
+        } else {
+            r.ox = world->ox; r.oy = world->oy; r.oz = world->oz; r.dx = world->dx; r.dy = world->dy; r.dz = world->dz;
+        }
+        r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;                     // math.rs:152
+        r.i = f2u(e.b.y);                      // the entry behind the marker
+        fetch_entry(ent, r.i, e);
+    }
     if (at_box) {
         if (COUNT) cnt.box++;
         uint32_t nxt = box_step(e.a, e.b, r, t_min);
@@ -269,6 +301,7 @@ __device__ __forceinline__ bool walk_trip(const float4* __restrict__ ent, uint32
     }
     // one fetch for every lane whose cursor moved in this trip (the address unit is busy for the
     // same 16-20 cycles per load instruction however few lanes take part)
+    static_assert(!(XF && RT_WALK_MERGE), "the merged fetch does not know the markers");
     if (RT_WALK_MERGE && (at_box || (run_prims && at_prim))) fetch_entry(ent, r.i, e);
     return true;
 }
@@ -335,12 +368,15 @@ __device__ __forceinline__ bool walk_trip_split(const float4* __restrict__ ent, 
     return true;
 }
 
-template <bool COUNT, bool OCT = false, bool TIE = OCT>
+template <bool COUNT, bool OCT = false, bool TIE = OCT, bool XF = false>
 __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
                                             bool valid, float ox,
                                             float oy, float oz, float dx, float dy, float dz,
-                                            float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
+                                            float t_min, float& best_t, uint32_t& best_prim, Counts& cnt,
+                                            const float4* __restrict__ xforms = nullptr) {
     static_assert(TIE || !OCT, "the octant copies are not in the reference's order");
+    static_assert(!(XF && OCT), "the octant copies do not carry the transform markers");
+    const WorldRay world{ox, oy, oz, dx, dy, dz};
     LaneRay r;
     lane_ray_init<TIE>(r, ox, oy, oz, dx, dy, dz, best_t);
     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(dx, dy, dz);   // the lane's copy
@@ -350,19 +386,9 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ ent, uint
     const float4 ended = make_float4(0.0f, 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
     LaneEntry e{ended, ended, ended, ended};
     if (valid) fetch_entry(ent, r.i, e);
-    while (walk_trip<COUNT, TIE>(ent, prim_wait, r, e, t_min, cnt)) {}
+    while (walk_trip<COUNT, TIE, XF>(ent, prim_wait, r, e, t_min, cnt, xforms, &world)) {}
     best_t = r.best_t;
     best_prim = key_result<TIE>(r.best_prim);
-}
-
-// glam's Mat4::transform_point3 (w = 1) / transform_vector3 (w = 0) on the four columns at m:
-// ((x_axis * x + y_axis * y) + z_axis * z) + w_axis * w in rounded f32 steps (no contraction here).
-__device__ __forceinline__ void xf_apply(const float4* __restrict__ m, float x, float y, float z, float w, float& ox,
-                                         float& oy, float& oz) {
-    const float4 c0 = m[0], c1 = m[1], c2 = m[2], c3 = m[3];
-    ox = c3.x * w + (c2.x * z + (c1.x * y + c0.x * x));
-    oy = c3.y * w + (c2.y * z + (c1.y * y + c0.y * x));
-    oz = c3.z * w + (c2.z * z + (c1.z * y + c0.z * x));
 }
 
 // What shading sees of a hit on a triangle of a TRANSFORMED mesh (shape.rs:298-307): the point is
@@ -382,54 +408,6 @@ __device__ __forceinline__ void xf_hit(const float4* __restrict__ xforms, const 
     const float len = sqrtf(dot3(wx, wy, wz, wx, wy, wz));
     nx = wx / len; ny = wy / len; nz = wz / len;
     front = dot3(ldx, ldy, ldz, nx, ny, nz) < 0.0f;
-}
-
-// Per-lane walk of a scene that holds transformed meshes: the linked units carry an ENTER marker
-// in front of such a mesh's tree and a LEAVE marker behind it (rt_internal.hpp: END_CODE_*).  At
-// ENTER the lane's ray goes to the mesh's local space, as Mesh::hit does before it descends
-// (shape.rs:454); t is the same parameter in both spaces, so best_t carries over; at LEAVE the
-// caller's ray is back.  Meshes are leaves, so one saved ray is enough.  A plain loop: every lane
-// handles whatever entry it stands at in every trip.
-template <bool COUNT, bool TIE>
-__device__ __forceinline__ void closest_hit_xf(const float4* __restrict__ ent, const float4* __restrict__ xforms,
-                                               bool valid, float ox, float oy, float oz, float dx, float dy, float dz,
-                                               float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
-    LaneRay r;
-    lane_ray_init<TIE>(r, ox, oy, oz, dx, dy, dz, best_t);
-    const float4 ended = make_float4(u2f(END_CODE_END), 0.0f, 0.0f, u2f(TAG_END << TAG_SHIFT));
-    float4 a = ended, b = ended;
-    if (valid) { a = ent[0]; b = ent[1]; }
-    for (;;) {
-        const uint32_t tag = f2u(a.w) >> TAG_SHIFT;
-        const bool done = tag == TAG_END && f2u(a.x) == END_CODE_END;
-        if (__ballot(!done) == 0ull) break;
-        if (tag == TAG_BOX) {
-            if (COUNT) cnt.box++;
-            r.i = box_step(a, b, r, t_min);
-        } else if (tag == TAG_TRI) {
-            if (COUNT) cnt.tri++;
-            const float4 c = ent[r.i + 2];
-            tri_step<TIE>(a, b, c, r, t_min);
-            r.i = f2u(c.w);
-        } else if (tag == TAG_SPH) {
-            if (COUNT) cnt.sph++;
-            sphere_step<TIE>(a, b, r, t_min);
-            r.i = f2u(b.y);
-        } else if (!done) {
-            if (f2u(a.x) == END_CODE_ENTER) {
-                const float4* inv = xforms + 8u * f2u(a.y) + 4u;
-                xf_apply(inv, ox, oy, oz, 1.0f, r.ox, r.oy, r.oz);
-                xf_apply(inv, dx, dy, dz, 0.0f, r.dx, r.dy, r.dz);
-            } else {
-                r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
-            }
-            r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;     // math.rs:152
-            r.i = f2u(b.y);
-        }
-        if (!done) { a = ent[r.i]; b = ent[r.i + 1]; }
-    }
-    best_t = r.best_t;
-    best_prim = key_result<TIE>(r.best_prim);
 }
 
 // math.rs:149-165 as a predicate (the same arithmetic as box_step)
@@ -894,7 +872,8 @@ extern __shared__ uint32_t lds_stack[];
 //        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
 //        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
-//        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only)
+//        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only),
+//        13 / 14 / 15 = 9 out of LDS / with idle lanes refilled / both (k_path only)
 template <bool COUNT, int SWEEP, bool TIE>
 __global__ void __launch_bounds__(RT_BLOCK)
 k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, float t_max,
@@ -939,7 +918,8 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
             else if (SWEEP == 9)
-                closest_hit_xf<COUNT, TIE>((const float4*)sc.walk, (const float4*)sc.xforms, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt);
+                closest_hit<COUNT, false, TIE, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt,
+                                                     (const float4*)sc.xforms);
             else if (SWEEP == 11)
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid,
@@ -1180,9 +1160,10 @@ __device__ unsigned long long rt_stamps[STAMP_SLOTS * STAMP_WAVES * 4];
 // (finish_ray + queueing) and take the next rays of the segment.  Every ray is still walked by one
 // lane in the reference's order; only which lane and when changes, and nothing downstream depends
 // on that (queues are compacted per kind, radiance is stored per path slot).
-template <bool COUNT, bool TIE, bool OCT = false, bool SPLIT = false>
+template <bool COUNT, bool TIE, bool OCT = false, bool SPLIT = false, bool XF = false>
 __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uint32_t n_ent_, uint32_t prim_wait,
-                                             uint32_t refill_min, const SplitCfg& sp, const float4* __restrict__ mats,
+                                             uint32_t refill_min, const SplitCfg& sp, const float4* __restrict__ xforms,
+                                             const float4* __restrict__ mats,
                                              const uint32_t* __restrict__ prim_meta, const float4* __restrict__ A,
                                              const float4* __restrict__ B, const float4* __restrict__ C,
                                              uint2* __restrict__ hits, uint32_t* __restrict__ q0,
@@ -1192,6 +1173,8 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                                              uint32_t& n1, uint32_t& n2, Counts& cnt) {
     static_assert(TIE || !OCT, "the octant copies are not in the reference's order");
     static_assert(!(TIE && SPLIT), "the split walk is a reference-order form");
+    static_assert(!(XF && (OCT || SPLIT)), "only the plain linked units carry the transform markers");
+    WorldRay world{0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f};
     LaneRay r;
     lane_ray_init<TIE>(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     uint32_t ray_i = 0, slot = 0;              // the lane's ray and its path slot
@@ -1203,14 +1186,18 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
     LaneEntry e{ended, ended, ended, ended};
     for (;;) {
         // (in the split walk a lane that waits for a unit from memory holds PEND_WORD there: it is live)
-        const bool live = SPLIT ? f2u(e.a.w) != ENDED_WORD : (f2u(e.a.w) >> TAG_SHIFT) != TAG_END;
+        const bool live = SPLIT ? f2u(e.a.w) != ENDED_WORD
+                          : XF  ? (f2u(e.a.w) >> TAG_SHIFT) != TAG_END || f2u(e.a.x) != END_CODE_END
+                                : (f2u(e.a.w) >> TAG_SHIFT) != TAG_END;
         const unsigned long long m_live = __ballot(live);
         const uint32_t n_idle = 64u - (uint32_t)__popcll(m_live);
         if (m_live == 0ull || (n_idle >= refill_min && next < n)) {
             uint32_t kind = 7u;
             if (has_ray && !live) {
-                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, r.dx, r.dy, r.dz, r.best_t,
-                                  key_result<TIE>(r.best_prim), last_depth, sky_intensity);
+                // (XF: a ray that ends inside a mesh's tree -- there is none: every tree is followed by its LEAVE
+                // marker -- would hold the local direction; the sky wants the caller's)
+                kind = finish_ray(mats, prim_meta, C, hits, Lbuf, ray_i, slot, XF ? world.dx : r.dx, XF ? world.dy : r.dy,
+                                  XF ? world.dz : r.dz, r.best_t, key_result<TIE>(r.best_prim), last_depth, sky_intensity);
                 has_ray = false;
             }
             uint32_t pos;
@@ -1228,6 +1215,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
                     ray_i = base + j;
                     const float4 ra = A[ray_i], rb = B[ray_i];
                     lane_ray_init<TIE>(r, ra.x, ra.y, ra.z, rb.x, rb.y, rb.z, __builtin_inff());
+                    if (XF) world = WorldRay{ra.x, ra.y, ra.z, rb.x, rb.y, rb.z};
                     slot = f2u(ra.w);
                     has_ray = true;
                     if (OCT) r.i = (n_ent_ + UNITS_END) * octant_of(rb.x, rb.y, rb.z);
@@ -1239,7 +1227,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
             }
         }
         if (SPLIT) walk_trip_split<COUNT>(ent, sp, prim_wait, r, e, t_min, cnt);
-        else walk_trip<COUNT, TIE>(ent, prim_wait, r, e, t_min, cnt);
+        else walk_trip<COUNT, TIE, XF>(ent, prim_wait, r, e, t_min, cnt, xforms, &world);
     }
 }
 
@@ -1348,11 +1336,15 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
         }
     } else if (SWEEP == 5 || SWEEP == 6) {
         walk_segment<COUNT, TIE>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
-                            sc.refill, SplitCfg{nullptr, 0u, 0u}, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base,
+                            sc.refill, SplitCfg{nullptr, 0u, 0u}, nullptr, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base,
                             n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
+    } else if (SWEEP == 14 || SWEEP == 15) {   // the refilled walk of a scene with transformed meshes
+        walk_segment<COUNT, TIE, false, false, true>(SWEEP == 15 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk,
+                            sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u}, (const float4*)sc.xforms, mats, sc.prim_meta, A, B, C,
+                            hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 10) {
         walk_segment<COUNT, false, false, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, sc.refill,
-                                         SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, mats, sc.prim_meta,
+                                         SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, nullptr, mats, sc.prim_meta,
                                          A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
                                          n1, n2, cnt);
     } else if (SWEEP == 12) {
@@ -1361,7 +1353,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                             q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
     } else if (SWEEP == 8) {
         walk_segment<COUNT, true, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
-                                  mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
+                                  nullptr, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
                                   sky_intensity, n0, n1, n2, cnt);
     } else {
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
@@ -1380,8 +1372,9 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                 closest_hit<COUNT, false, TIE>((const float4*)lds_stack, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             else if (SWEEP == 7)
                 closest_hit<COUNT, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
-            else if (SWEEP == 9)
-                closest_hit_xf<COUNT, TIE>((const float4*)sc.walk, (const float4*)sc.xforms, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 9 || SWEEP == 13)    // a scene with transformed meshes, from memory or out of LDS
+                closest_hit<COUNT, false, TIE, true>(SWEEP == 13 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid,
+                                                     a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt, (const float4*)sc.xforms);
             else if (SWEEP == 11)
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
@@ -1616,14 +1609,16 @@ __device__ __forceinline__ void stage_fence() {
 #ifndef RT_LDS_BLOCK
 #define RT_LDS_BLOCK 512
 #endif
+// (the forms that keep a copy of the units, or of their top, in LDS: workgroups of eight waves)
+constexpr bool lds_form(int sweep) { return sweep == 4 || sweep == 6 || sweep == 10 || sweep == 13 || sweep == 15; }
 template <int SWEEP, bool TIE>
-__global__ void __launch_bounds__(SWEEP == 4 || SWEEP == 6 || SWEEP == 10 ? RT_LDS_BLOCK : RT_WAVE)
+__global__ void __launch_bounds__(lds_form(SWEEP) ? RT_LDS_BLOCK : RT_WAVE)
     __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
        uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
-    const uint32_t wpb = SWEEP == 4 || SWEEP == 6 || SWEEP == 10 ? RT_LDS_BLOCK / 64 : RT_WPB;
+    const uint32_t wpb = lds_form(SWEEP) ? RT_LDS_BLOCK / 64 : RT_WPB;
     const uint32_t seg = blockIdx.x * wpb + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (SWEEP == 4 || SWEEP == 6 || SWEEP == 10) {
+    if (lds_form(SWEEP)) {
         const float4* src = (const float4*)sc.walk;
         float4* dst = (float4*)lds_stack;
         const uint32_t n_copy = SWEEP == 10 ? sc.split_top : sc.n_walk + UNITS_END;   // (split walk: the top only)
@@ -1829,7 +1824,17 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
     if (sc.wide) { if (sc.refill) RT_PATH_T(12, true); else RT_PATH_T(11, true); return check_launch(); }
-    if (sc.n_xforms) { RT_PATH(9); return check_launch(); }
+    if (sc.n_xforms) {                         // the per-lane walks that follow the transform markers
+        if (sc.lds_walk) {
+            const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
+            if (sc.refill) RT_PATH_LDS(15); else RT_PATH_LDS(13);
+        } else if (sc.refill) {
+            RT_PATH(14);
+        } else {
+            RT_PATH(9);
+        }
+        return check_launch();
+    }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
         if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);

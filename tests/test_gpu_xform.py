@@ -61,6 +61,56 @@ def test_world2_with_translated_planes(rt, ob, ctx):
     _compare(rt, ob, ctx, osc, 96, 96, 48, 6, clip=6.0)
 
 
+@pytest.mark.parametrize("scene", ["nested", "world2_planes"])
+def test_transformed_meshes_in_every_per_lane_form(rt, ob, ctx, scene, monkeypatch, capfd):
+    """A scene with transformed meshes is traced by every per-lane form -- from memory or out of LDS,
+    plain or with idle lanes refilled, on the reference's trees or the surface-area trees -- and the
+    frame is the staged launches' frame bit for bit whichever form runs; the defaults time them
+    all on the first render.  world2 with its two translated planes fits LDS and renders from there."""
+    if scene == "nested":
+        mats, objects = _nested_description(ob, 83, True)
+        cam = ((6.0, -7.0, 4.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.05, 9.0)
+        osc = ob.Scene.from_description(mats, objects, 0, camera=cam, sky=0.8)
+    else:
+        osc = ob.Scene.world2(asset("thing.obj"), 2)
+    w, h, spp = 128, 96, 16
+    pc = product_camera(rt, osc, w, h)
+    p = rt.Scene.params(w, h, spp, 6, osc.sky)
+    rays = osc.record_rays(96, 72, 2, 6, cap=60_000)
+    want, _ = osc.trace(rays)
+    strict = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=rt.BUILD_REFERENCE)
+    staged, st0 = strict.render(pc, rt.Scene.params(w, h, spp, 6, osc.sky, flags=rt.RENDER_STAGED))
+    seen = set()
+    for build in (rt.BUILD_REFERENCE, rt.BUILD_SAH):
+        for lds in (True, False):
+            for refill in ("0", "16"):
+                monkeypatch.setenv("RT_REFILL", refill)
+                if not lds:
+                    monkeypatch.setenv("RT_NO_LDS_WALK", "1")
+                sc = rt.Scene(ctx, osc.materials(), osc.objects(), osc.root_kind, build=build)
+                monkeypatch.delenv("RT_NO_LDS_WALK", raising=False)
+                sc.set_traversal(rt.TRAVERSAL_PER_LANE)
+                img, st = sc.render(pc, p)
+                seen.add((rt.TREE_NAMES[st["tree"]], rt.FORM_NAMES[st["kernel_form"]]))
+                assert st["rays_traced"] == st0["rays_traced"] and np.array_equal(img.view(np.uint32), staged.view(np.uint32))
+                assert_hits_equal(sc.trace(rays), want)
+                sc.close()
+    monkeypatch.delenv("RT_REFILL")
+    assert seen == {(t, f) for t in ("reference", "sah") for f in ("walk", "walk_refill", "walk_lds", "walk_lds_refill")}
+    monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
+    sc = mirror(rt, ctx, osc)                                  # the defaults
+    capfd.readouterr()
+    img, st = sc.render(pc, p)
+    probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    with capfd.disabled():
+        print(f"\n{scene}: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree")
+    assert len(probes) == 2 and "lds" in rt.FORM_NAMES[st["kernel_form"]]     # both scenes fit LDS: one form per tree
+    assert np.array_equal(img.view(np.uint32), staged.view(np.uint32))
+    assert_hits_equal(sc.trace(rays), want)
+    sc.close()
+    strict.close()
+
+
 def test_transformed_scene_image_and_staged_launches(rt, ob, ctx):
     mats, objects = _nested_description(ob, 83, True)
     cam = ((6.0, -7.0, 4.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.05, 9.0)
