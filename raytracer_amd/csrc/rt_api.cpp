@@ -806,9 +806,12 @@ int rt_scene_commit(rt_scene* s) {
     if (s->open_groups.size() != 1) return fail(RT_ERR_STATE, "rt_scene_commit: a container opened with rt_scene_begin_group is not closed");
     // Which trees the scene gets: the reference's (REFERENCE, AUTO) and / or the surface-area ones (SAH,
     // AUTO).  A scene without a GPU shows one tree to its inspectors and builds no second one.
-    // (Only the trees inside meshes differ between the two; a mesh of up to two triangles has one shape.)
-    bool splits_differ = false;
+    // (The two differ in how meshes of more than two triangles and containers of more than two objects
+    // are split; a scene without either has one shape.)
+    bool splits_differ = s->root_kind == RT_ROOT_BVH && s->groups[0].items.size() > 2;
     for (const SceneObject& o : s->objects) splits_differ = splits_differ || (o.is_mesh && o.tris.size() > 2);
+    for (size_t g = 1; g < s->groups.size(); g++)
+        splits_differ = splits_differ || (s->groups[g].kind == RT_ROOT_BVH && s->groups[g].items.size() > 2);
     const bool want_ref = s->build_mode != RT_BUILD_SAH;
     const bool want_fast = s->build_mode == RT_BUILD_SAH || (s->build_mode == RT_BUILD_AUTO && s->ctx != nullptr && splits_differ);
     // with a cache directory: the flattened arrays come from the file of this description's key when

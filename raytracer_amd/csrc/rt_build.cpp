@@ -468,10 +468,21 @@ struct Builder {
             close_box(bx);
             return b;
         }
-        std::stable_sort(ids, ids + n, [this, axis](long a, long b) {
-            return item_box(a).lo[axis] < item_box(b).lo[axis];
-        });
         size_t half = n / 2;
+        if (sah) {
+            // The surface-area trees split the objects of a Bvh too: where a 16-bin surface-area heuristic
+            // over the centres of their boxes is cheapest (the median of min[axis] where the centres give
+            // no split).  One sphere as large as the scene then parts from the rest near the root instead
+            // of widening the boxes of a whole branch.  Boxes stay the plain unions of Bvh::new.
+            if (!sah_split_items(ids, n, half)) {
+                std::stable_sort(ids, ids + n, [this, axis](long a, long b) { return item_box(a).lo[axis] < item_box(b).lo[axis]; });
+                half = n / 2;
+            }
+        } else {
+            std::stable_sort(ids, ids + n, [this, axis](long a, long b) {
+                return item_box(a).lo[axis] < item_box(b).lo[axis];
+            });
+        }
         size_t bx = dry ? 0 : push_box(Box{});  // box is known only after both children exist
         Box l = emit_bvh(ids, half, (axis + 1) % 3, dry);
         Box r = emit_bvh(ids + half, n - half, (axis + 1) % 3, dry);
@@ -483,6 +494,64 @@ struct Builder {
         close_box(bx);
         return b;
     }
+    // partitions ids[0..n) (n >= 3) at the cheapest of the 3 x 15 binned surface-area splits; false when
+    // the centres of the boxes give none
+    bool sah_split_items(long* ids, size_t n, size_t& half) const {
+        constexpr int BINS = 16;
+        auto centre2 = [this](long it, int k) { const Box& b = item_box(it); return b.lo[k] + b.hi[k]; };
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++) {
+                const float c = centre2(ids[i], k);
+                if (c == c) { clo[k] = std::min(clo[k], c); chi[k] = std::max(chi[k], c); }
+            }
+        float best = INFINITY, best_scale = 0.0f;
+        int best_axis = -1, best_bin = 0;
+        for (int k = 0; k < 3; k++) {
+            const float ext = chi[k] - clo[k];
+            if (!(ext > 0.0f) || !(ext < INFINITY)) continue;
+            const float scale = (float)BINS * (1.0f - 1e-6f) / ext;
+            Box bb[BINS];
+            size_t cnt[BINS] = {};
+            for (int j = 0; j < BINS; j++) bb[j] = box_infinity();
+            for (size_t i = 0; i < n; i++) {
+                const float c = centre2(ids[i], k);
+                const int j = c == c ? std::min(BINS - 1, std::max(0, (int)((c - clo[k]) * scale))) : 0;
+                bb[j] = surrounding(bb[j], item_box(ids[i]));
+                cnt[j]++;
+            }
+            float right_area[BINS];
+            size_t right_cnt[BINS];
+            Box acc = box_infinity();
+            size_t c = 0;
+            for (int j = BINS - 1; j > 0; j--) {
+                if (cnt[j]) acc = surrounding(acc, bb[j]);
+                c += cnt[j];
+                right_area[j] = c ? half_area(acc) : 0.0f;
+                right_cnt[j] = c;
+            }
+            acc = box_infinity();
+            c = 0;
+            for (int j = 0; j + 1 < BINS; j++) {
+                if (cnt[j]) acc = surrounding(acc, bb[j]);
+                c += cnt[j];
+                if (c == 0 || right_cnt[j + 1] == 0) continue;
+                const float cost = half_area(acc) * (float)c + right_area[j + 1] * (float)right_cnt[j + 1];
+                if (cost < best) { best = cost; best_axis = k; best_bin = j; best_scale = scale; }
+            }
+        }
+        if (best_axis < 0) return false;
+        const int k = best_axis;
+        const float lo = clo[k];
+        long* mid = std::stable_partition(ids, ids + n, [&](long it) {
+            const float c = centre2(it, k);
+            const int j = c == c ? std::min(BINS - 1, std::max(0, (int)((c - lo) * best_scale))) : 0;
+            return j <= best_bin;
+        });
+        half = (size_t)(mid - ids);
+        return half > 0 && half < n;
+    }
+
     // get_aabb() of every container, innermost first (a container's index is above its parent's)
     void compute_group_boxes() {
         group_box.assign(groups->size(), box_infinity());
@@ -778,7 +847,7 @@ constexpr char CACHE_MAGIC[8] = {'R', 'T', 'A', 'M', 'D', 'S', 'C', '4'};
 // Version of what the builder writes into the arrays (tree construction, entry and unit formats,
 // primitive keys, layout rules).  It is part of the cache key: bump it with any change to the
 // output of this file, and files of older builders are simply never found.
-constexpr uint32_t BUILDER_VERSION = 5;
+constexpr uint32_t BUILDER_VERSION = 6;
 struct CacheHeader {
     char magic[8];
     uint64_t key;

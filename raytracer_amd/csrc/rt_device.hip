@@ -1356,12 +1356,26 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                   nullptr, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
                                   sky_intensity, n0, n1, n2, cnt);
     } else {
+        // (RT_PREFETCH_RAYS: the next group's ray records are requested before this group is walked, so
+        // their latency runs under the walk instead of in front of the next one)
+#ifndef RT_PREFETCH_RAYS
+#define RT_PREFETCH_RAYS 1
+#endif
+        const float4 no_a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), no_b = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        float4 a_next = no_a, b_next = no_b;
+        if (RT_PREFETCH_RAYS && lane < n) { a_next = A[base + lane]; b_next = B[base + lane]; }
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t i = base + j0 + lane;
             const bool valid = j0 + lane < n;
             uint32_t kind = 7u;
-            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            if (valid) { a = A[i]; b = B[i]; }
+            float4 a = no_a, b = no_b;
+            if (RT_PREFETCH_RAYS) {
+                a = a_next; b = b_next;
+                a_next = no_a; b_next = no_b;
+                if (j0 + 64u + lane < n) { a_next = A[i + 64u]; b_next = B[i + 64u]; }
+            } else if (valid) {
+                a = A[i]; b = B[i];
+            }
             float t = t_max;
             uint32_t prim;
             if (SWEEP == 3)

@@ -97,7 +97,7 @@ def test_soup_sah_tree(rt, ob, ctx, soup):
     try:
         world = rt.World.soup(ctx, N_TRIS, grid=64, seed=12345)
     finally:
-        rt.set_default_build(rt.BUILD_REFERENCE)
+        rt.set_default_build(rt.BUILD_AUTO)
     for mode, label in ((rt.TRAVERSAL_PER_LANE, "SAH tree, per-lane walk"), (rt.TRAVERSAL_OCTANT, "SAH tree, octant walk"),
                         (rt.TRAVERSAL_WIDE, "SAH tree collapsed to eight-child nodes, wide walk")):
         world.scene.set_traversal(mode)

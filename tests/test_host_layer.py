@@ -538,6 +538,7 @@ def test_sah_build_keeps_format_and_hits(rt, ob, leaf, monkeypatch):
     assert sorted(u[tags != 0, 7].tolist()) == list(range(sah.num_prims))       # each primitive once
     end_of = lambda i: int(u[i, 3] & 0x3FFFFFFF) if tags[i] == 0 else i + 1
     pad = np.float32(0.0001)
+    mesh_of_prim = np.concatenate([np.full(len(o[1]), k if o[0] == "mesh" else -1 - k) for k, o in enumerate(objects)])
     big_leaves = 0
     for i in np.nonzero(tags == 0)[0]:
         end = end_of(i)
@@ -553,7 +554,9 @@ def test_sah_build_keeps_format_and_hits(rt, ob, leaf, monkeypatch):
             assert first == end or end_of(first) == end
         kids = np.arange(i + 1, end)
         tri = kids[tags[kids] == 1]
-        if len(kids) + 1 == 2 * len(tri) - 1:              # a node of a mesh tree: n leaves, n - 1 boxes
+        # a node of a mesh tree: n leaves of ONE mesh, n - 1 boxes (the surface-area split also re-groups the
+        # objects of a Bvh, whose boxes are plain unions: two small meshes under one such box do not count)
+        if len(kids) + 1 == 2 * len(tri) - 1 and len(set(mesh_of_prim[u[tri, 7]].tolist())) == 1:
             p0 = ent[tri, 0:3]
             pts = np.concatenate([p0, p0 + ent[tri, 4:7], p0 + ent[tri, 8:11]])
             # vertices are stored as p0 and two edges; the sums round, so compare loosely
@@ -758,7 +761,7 @@ def test_scene_cache_round_trip(rt, ob, tmp_path, monkeypatch):
         assert c.scene.cache_state == rt.CACHE_STORED and len(list(tmp_path.glob("*.rtscene"))) == 2
         rt.set_default_build(rt.BUILD_SAH)
         d = rt.World.soup(None, 500_000, grid=16, seed=77)
-        rt.set_default_build(rt.BUILD_REFERENCE)
+        rt.set_default_build(rt.BUILD_AUTO)
         assert d.scene.cache_state == rt.CACHE_STORED
         monkeypatch.setenv("RT_LAYOUT_TOP", "0")
         e = rt.World.soup(None, 500_000, grid=16, seed=77)
@@ -787,7 +790,7 @@ def test_scene_cache_round_trip(rt, ob, tmp_path, monkeypatch):
         assert s3.cache_state == rt.CACHE_STORE_FAILED and s3.num_prims == s1.num_prims
     finally:
         rt.set_default_cache_dir(None)
-        rt.set_default_build(rt.BUILD_REFERENCE)
+        rt.set_default_build(rt.BUILD_AUTO)
 
 
 def test_progressive_schedule_and_ppm(rt, tmp_path):

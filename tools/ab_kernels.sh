@@ -18,7 +18,7 @@ for wl in $wls; do
             [ "$lib" != default ] && envs+=("RT_AMD_LIB=$PWD/$lib")
             [ "$lay" != "-" ] && IFS=, read -ra more <<< "$lay" && envs+=("${more[@]}")
             label="$wl $lib $lay"
-            env "${envs[@]}" timeout -k 10 400 python3 -u bench.py --no-cpu --workload $wl $extra 2>/dev/null | tail -n 1 | python3 -c "
+            env "${envs[@]}" timeout -k 10 400 python3 -u bench.py --no-cpu --no-reference-leg --workload $wl $extra 2>/dev/null | tail -n 1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); d['label']='$label'; print(json.dumps(d))" >> $out || echo "FAILED $label" >> $out
         done
