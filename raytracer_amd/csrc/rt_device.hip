@@ -1096,10 +1096,93 @@ k_raygen(rt_camera cam, BatchGeom g, uint32_t seed_lo, uint32_t seed_hi, float4*
 #endif  // RT_HAS_SWEEP
 
 // ---------------------------------------------------------------------------------------------
-// trace: closest hit for every live ray of the wave's segment, terminate or queue by kind
+// Material::scatter (material.rs) for one ray (a, b, c: origin + path slot, direction + rng key,
+// throughput + rng key) that hit `prim` at t: the scattered ray in (na, nb, nc); false when the
+// material absorbs it (scatter() == false: the path ends with what it has emitted).
 // ---------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ bool shade_one(const DevScene& sc, const float4& a, const float4& b, const float4& c, float t,
+                                          uint32_t prim, uint32_t ctr, float4& na, float4& nb, float4& nc) {
+    const float4* geo = (const float4*)sc.prim_geo;
+    const float4* mats = (const float4*)sc.materials;
+    bool alive = false;
+    {
+        const uint32_t id = key_rank(prim);
+        const uint32_t meta = sc.prim_meta[id];
+        const float4 g = geo[id];
+        const float4 m0 = mats[2 * (meta & MAT_MASK)];
+        const uint32_t klo = f2u(b.w), khi = f2u(c.w);
+        // hit point and face-forwarded normal
+        float px = a.x + b.x * t, py = a.y + b.y * t, pz = a.z + b.z * t;
+        float nx, ny, nz;
+        if (meta & META_SPHERE) {
+            nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
+        } else {
+            const bool bf = (prim & PRIM_BACKFACE) != 0;
+            nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
+        }
+        bool front = dot3(b.x, b.y, b.z, nx, ny, nz) < 0.0f;
+        if (sc.n_xforms != 0u && !(meta & META_SPHERE) && f2u(g.w) != 0u)   // a triangle of a transformed mesh
+            xf_hit((const float4*)sc.xforms, g, (prim & PRIM_BACKFACE) != 0, a.x, a.y, a.z, b.x, b.y, b.z, t, px, py, pz,
+                   nx, ny, nz, front);
+        if (!front) { nx = -nx; ny = -ny; nz = -nz; }
+        float ddx, ddy, ddz, ar = m0.x, ag = m0.y, ab = m0.z;
+        if (KIND == RT_MAT_LAMBERT) {                  // material.rs:27-56
+            float sx, sy, sz;
+            sample_sphere(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), sx, sy, sz);
+            float ex = nx + sx, ey = ny + sy, ez = nz + sz;
+            if (fabsf(ex) + fabsf(ey) + fabsf(ez) < 1.1920929e-7f) { ex = nx; ey = ny; ez = nz; }
+            const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+            ddx = ex / len; ddy = ey / len; ddz = ez / len;
+            const float4 m1 = mats[2 * (meta & MAT_MASK) + 1];
+            if (f2u(m1.y) & RT_MAT_FLAG_NORMAL_SHADING) {
+                ar = (nx + 1.0f) * 0.5f; ag = (ny + 1.0f) * 0.5f; ab = (nz + 1.0f) * 0.5f;
+            }
+            alive = true;
+        } else if (KIND == RT_MAT_METAL) {             // material.rs:63-80
+            const float dn2 = 2.0f * dot3(b.x, b.y, b.z, nx, ny, nz);
+            const float rx = b.x - dn2 * nx, ry = b.y - dn2 * ny, rz = b.z - dn2 * nz;
+            float sx, sy, sz;
+            sample_ball(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), rng_f01(klo, khi, ctr + 2u),
+                        sx, sy, sz);
+            ddx = rx + m0.w * sx; ddy = ry + m0.w * sy; ddz = rz + m0.w * sz;
+            alive = dot3(rx, ry, rz, nx, ny, nz) > 0.0f;
+        } else {                                       // material.rs:87-120
+            const float ratio = front ? 1.0f / m0.w : m0.w;
+            const float len = sqrtf(dot3(b.x, b.y, b.z, b.x, b.y, b.z));
+            const float ux = b.x / len, uy = b.y / len, uz = b.z / len;
+            const float cos_t = fminf(dot3(-ux, -uy, -uz, nx, ny, nz), 1.0f);
+            const float sin_t = sqrtf(1.0f - cos_t * cos_t);
+            bool refl = ratio * sin_t > 1.0f;
+            if (!refl) {                               // reflectance (math.rs:105-110)
+                float r0 = (1.0f - ratio) / (1.0f + ratio);
+                r0 = r0 * r0;
+                const float om = 1.0f - cos_t;
+                const float om2 = om * om;
+                refl = r0 + (1.0f - r0) * (om2 * om2 * om) > rng_f01(klo, khi, ctr);
+            }
+            if (refl) {                                // reflect (math.rs:94-96)
+                const float dn2 = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
+                ddx = ux - dn2 * nx; ddy = uy - dn2 * ny; ddz = uz - dn2 * nz;
+            } else {                                   // refract (math.rs:98-103)
+                const float ppx = ratio * (ux + cos_t * nx), ppy = ratio * (uy + cos_t * ny),
+                            ppz = ratio * (uz + cos_t * nz);
+                const float par = -sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
+                ddx = ppx + par * nx; ddy = ppy + par * ny; ddz = ppz + par * nz;
+            }
+            alive = true;
+        }
+        na = make_float4(px, py, pz, a.w);
+        nb = make_float4(ddx, ddy, ddz, b.w);
+        nc = make_float4(c.x * ar, c.y * ag, c.z * ab, c.w);
+    }
+    return alive;
+}
+
 // what happens to a traced ray: terminate it (sky, emitter, depth cap -> its radiance goes to
 // Lbuf) or record the hit and report the material kind it must be queued under (7 = none)
+// RECORD = false: the caller shades the ray itself right away and needs no hit record.
+template <bool RECORD = true>
 __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
                                                const float4* __restrict__ C, uint2* __restrict__ hits,
                                                float4* __restrict__ Lbuf, uint32_t i, uint32_t slot, float dx,
@@ -1128,7 +1211,7 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
         Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return 7u;
     }
-    hits[i] = make_uint2(f2u(t), prim);
+    if (RECORD) hits[i] = make_uint2(f2u(t), prim);
     return k;
 }
 
@@ -1292,14 +1375,47 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
 // Closest hit for the n live rays of the segment at `base`: terminates paths (sky, emitter, depth
 // cap) or records the hit and queues the ray under its material kind; n0 / n1 / n2 return the
 // queue lengths.  Whole wave, converged.
-template <bool COUNT, int SWEEP, bool TIE>
+// FUSE >= 0 (the fused kernel): a ray that hits a scattering material is shaded in registers right
+// after its closest hit -- no hit record, no queue, no second pass over the ray records -- and the
+// scattered ray goes straight to the segment's place in the next ray buffer (fuse->out counts them).
+// FUSE = RT_MAT_LAMBERT: scenes whose only scattering kind is Lambertian (the next depth then sees
+// the segment the queue would have given it, bit for bit); FUSE_ANY: every kind, one after the
+// other under the lanes' masks (the next depth's rays then stand in ray order instead of sorted by
+// material, which changes no path: a path's random numbers are keyed by pixel, sample and depth).
+constexpr int FUSE_ANY = 7;
+struct FuseOut {
+    float4 *nA, *nB, *nC;      // the next depth's ray records
+    uint32_t ctr;              // RNG counter base of this depth
+    uint32_t out;              // scattered rays so far
+};
+template <bool COUNT, int SWEEP, bool TIE, int FUSE = -1>
 __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* __restrict__ A,
                                               const float4* __restrict__ B, const float4* __restrict__ C,
                                               uint2* __restrict__ hits, uint32_t* __restrict__ q0,
                                               uint32_t* __restrict__ q1, uint32_t* __restrict__ q2,
                                               float4* __restrict__ Lbuf, uint32_t base, uint32_t n, uint32_t lane,
                                               uint32_t last_depth, float t_min, float sky_intensity, uint32_t& n0,
-                                              uint32_t& n1, uint32_t& n2, Counts& cnt) {
+                                              uint32_t& n1, uint32_t& n2, Counts& cnt, FuseOut* fuse = nullptr) {
+    static_assert(FUSE < 0 || SWEEP == 0 || SWEEP == 1 || SWEEP == 2 || SWEEP == 4, "forms with a fused shade");
+    // shades ray i (records a, b; hit t, prim) when its material kind is FUSE; appends the scattered ray
+    auto shade_now = [&](uint32_t kind, uint32_t i, const float4& a, const float4& b, float t, uint32_t prim) {
+        bool alive = false;
+        float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
+        const bool scatters = FUSE == FUSE_ANY ? kind < 3u : kind == (uint32_t)FUSE;
+        if (scatters) {
+            const float4 c = C[i];
+            if (FUSE == FUSE_ANY) {
+                if (kind == RT_MAT_LAMBERT) alive = shade_one<RT_MAT_LAMBERT>(sc, a, b, c, t, prim, fuse->ctr, na, nb, nc);
+                else if (kind == RT_MAT_METAL) alive = shade_one<RT_MAT_METAL>(sc, a, b, c, t, prim, fuse->ctr, na, nb, nc);
+                else alive = shade_one<RT_MAT_DIELECTRIC>(sc, a, b, c, t, prim, fuse->ctr, na, nb, nc);
+            } else {
+                alive = shade_one<(FUSE >= 0 && FUSE < 3 ? FUSE : 0)>(sc, a, b, c, t, prim, fuse->ctr, na, nb, nc);
+            }
+        }
+        const uint32_t pos = base + wave_append(alive, fuse->out);
+        if (alive) { fuse->nA[pos] = na; fuse->nB[pos] = nb; fuse->nC[pos] = nc; }
+        else if (scatters) Lbuf[f2u(a.w)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // scatter() == false
+    };
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
     const float t_max = __builtin_inff();                  // main.rs:46: t_max = f32::INFINITY
@@ -1327,12 +1443,17 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                       f32x2{a0.z, a1.z}, f32x2{b0.x, b1.x}, f32x2{b0.y, b1.y}, f32x2{b0.z, b1.z},
                                       t_min, t_max, h, cnt);
             uint32_t ka = 7u, kb = 7u;
-            if (va) ka = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0],
-                                    h.prim[0], last_depth, sky_intensity);
-            if (vb) kb = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1],
-                                    h.prim[1], last_depth, sky_intensity);
-            enqueue(ka, ia);
-            enqueue(kb, ib);
+            if (va) ka = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0],
+                                                h.prim[0], last_depth, sky_intensity);
+            if (vb) kb = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1],
+                                                h.prim[1], last_depth, sky_intensity);
+            if (FUSE >= 0) {
+                shade_now(ka, ia, a0, b0, h.t[0], h.prim[0]);
+                shade_now(kb, ib, a1, b1, h.t[1], h.prim[1]);
+            } else {
+                enqueue(ka, ia);
+                enqueue(kb, ib);
+            }
         }
     } else if (SWEEP == 5 || SWEEP == 6) {
         walk_segment<COUNT, TIE>(SWEEP == 6 ? (const float4*)lds_stack : (const float4*)sc.walk, sc.n_walk, sc.prim_wait,
@@ -1396,9 +1517,10 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             else
                 closest_hit<COUNT, false, TIE>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
-                kind = finish_ray(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
-                                  sky_intensity);
-            enqueue(kind, i);
+                kind = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
+                                              sky_intensity);
+            if (FUSE >= 0) shade_now(kind, i, a, b, t, prim);
+            else enqueue(kind, i);
         }
     }
 }
@@ -1463,8 +1585,6 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
                                             float4* __restrict__ nA, float4* __restrict__ nB,
                                             float4* __restrict__ nC, float4* __restrict__ Lbuf, uint32_t base,
                                             uint32_t n, uint32_t ctr, uint32_t lane, uint32_t& out) {
-    const float4* geo = (const float4*)sc.prim_geo;
-    const float4* mats = (const float4*)sc.materials;
     for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
         const bool valid = j0 + lane < n;
         bool alive = false;
@@ -1474,76 +1594,8 @@ __device__ __forceinline__ void shade_queue(const DevScene& sc, const float4* __
             const uint32_t i = queue[base + j0 + lane];
             const float4 a = A[i], b = B[i], c = C[i];
             const uint2 h = hits[i];
-            const float t = u2f(h.x);
-            const uint32_t id = key_rank(h.y);
-            const uint32_t meta = sc.prim_meta[id];
-            const float4 g = geo[id];
-            const float4 m0 = mats[2 * (meta & MAT_MASK)];
-            const uint32_t klo = f2u(b.w), khi = f2u(c.w);
             slot = f2u(a.w);
-            // hit point and face-forwarded normal
-            float px = a.x + b.x * t, py = a.y + b.y * t, pz = a.z + b.z * t;
-            float nx, ny, nz;
-            if (meta & META_SPHERE) {
-                nx = (px - g.x) / g.w; ny = (py - g.y) / g.w; nz = (pz - g.z) / g.w;
-            } else {
-                const bool bf = (h.y & PRIM_BACKFACE) != 0;
-                nx = bf ? -g.x : g.x; ny = bf ? -g.y : g.y; nz = bf ? -g.z : g.z;
-            }
-            bool front = dot3(b.x, b.y, b.z, nx, ny, nz) < 0.0f;
-            if (sc.n_xforms != 0u && !(meta & META_SPHERE) && f2u(g.w) != 0u)   // a triangle of a transformed mesh
-                xf_hit((const float4*)sc.xforms, g, (h.y & PRIM_BACKFACE) != 0, a.x, a.y, a.z, b.x, b.y, b.z, t, px, py, pz,
-                       nx, ny, nz, front);
-            if (!front) { nx = -nx; ny = -ny; nz = -nz; }
-            float ddx, ddy, ddz, ar = m0.x, ag = m0.y, ab = m0.z;
-            if (KIND == RT_MAT_LAMBERT) {                  // material.rs:27-56
-                float sx, sy, sz;
-                sample_sphere(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), sx, sy, sz);
-                float ex = nx + sx, ey = ny + sy, ez = nz + sz;
-                if (fabsf(ex) + fabsf(ey) + fabsf(ez) < 1.1920929e-7f) { ex = nx; ey = ny; ez = nz; }
-                const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
-                ddx = ex / len; ddy = ey / len; ddz = ez / len;
-                const float4 m1 = mats[2 * (meta & MAT_MASK) + 1];
-                if (f2u(m1.y) & RT_MAT_FLAG_NORMAL_SHADING) {
-                    ar = (nx + 1.0f) * 0.5f; ag = (ny + 1.0f) * 0.5f; ab = (nz + 1.0f) * 0.5f;
-                }
-                alive = true;
-            } else if (KIND == RT_MAT_METAL) {             // material.rs:63-80
-                const float dn2 = 2.0f * dot3(b.x, b.y, b.z, nx, ny, nz);
-                const float rx = b.x - dn2 * nx, ry = b.y - dn2 * ny, rz = b.z - dn2 * nz;
-                float sx, sy, sz;
-                sample_ball(rng_f01(klo, khi, ctr), rng_f01(klo, khi, ctr + 1u), rng_f01(klo, khi, ctr + 2u),
-                            sx, sy, sz);
-                ddx = rx + m0.w * sx; ddy = ry + m0.w * sy; ddz = rz + m0.w * sz;
-                alive = dot3(rx, ry, rz, nx, ny, nz) > 0.0f;
-            } else {                                       // material.rs:87-120
-                const float ratio = front ? 1.0f / m0.w : m0.w;
-                const float len = sqrtf(dot3(b.x, b.y, b.z, b.x, b.y, b.z));
-                const float ux = b.x / len, uy = b.y / len, uz = b.z / len;
-                const float cos_t = fminf(dot3(-ux, -uy, -uz, nx, ny, nz), 1.0f);
-                const float sin_t = sqrtf(1.0f - cos_t * cos_t);
-                bool refl = ratio * sin_t > 1.0f;
-                if (!refl) {                               // reflectance (math.rs:105-110)
-                    float r0 = (1.0f - ratio) / (1.0f + ratio);
-                    r0 = r0 * r0;
-                    const float om = 1.0f - cos_t;
-                    const float om2 = om * om;
-                    refl = r0 + (1.0f - r0) * (om2 * om2 * om) > rng_f01(klo, khi, ctr);
-                }
-                if (refl) {                                // reflect (math.rs:94-96)
-                    const float dn2 = 2.0f * dot3(ux, uy, uz, nx, ny, nz);
-                    ddx = ux - dn2 * nx; ddy = uy - dn2 * ny; ddz = uz - dn2 * nz;
-                } else {                                   // refract (math.rs:98-103)
-                    const float ppx = ratio * (ux + cos_t * nx), ppy = ratio * (uy + cos_t * ny),
-                                ppz = ratio * (uz + cos_t * nz);
-                    const float par = -sqrtf(fabsf(1.0f - dot3(ppx, ppy, ppz, ppx, ppy, ppz)));
-                    ddx = ppx + par * nx; ddy = ppy + par * ny; ddz = ppz + par * nz;
-                }
-                alive = true;
-            }
-            na = make_float4(px, py, pz, a.w);
-            nb = make_float4(ddx, ddy, ddz, b.w);
-            nc = make_float4(c.x * ar, c.y * ag, c.z * ab, c.w);
+            alive = shade_one<KIND>(sc, a, b, c, u2f(h.x), h.y, ctr, na, nb, nc);
         }
         const uint32_t pos = base + wave_append(alive, out);
         if (alive) { nA[pos] = na; nB[pos] = nb; nC[pos] = nc; }
@@ -1625,7 +1677,7 @@ __device__ __forceinline__ void stage_fence() {
 #endif
 // (the forms that keep a copy of the units, or of their top, in LDS: workgroups of eight waves)
 constexpr bool lds_form(int sweep) { return sweep == 4 || sweep == 6 || sweep == 10 || sweep == 13 || sweep == 15; }
-template <int SWEEP, bool TIE>
+template <int SWEEP, bool TIE, int FUSE = -1>
 __global__ void __launch_bounds__(lds_form(SWEEP) ? RT_LDS_BLOCK : RT_WAVE)
     __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
@@ -1660,6 +1712,13 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
         const bool last = d + 1u == max_bounces;
         stage_fence();
         uint32_t n0, n1, n2;
+        if (FUSE >= 0) {                                   // closest hit and shade in one pass over the segment
+            FuseOut fuse{nA, nB, nC, d * 16u, 0u};
+            trace_segment<false, SWEEP, TIE, FUSE>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
+                                                   t_min, sky_intensity, n0, n1, n2, cnt, &fuse);
+            n = fuse.out;
+            continue;
+        }
 #ifdef RT_UTIL
         trace_segment<true, SWEEP, TIE>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
                                    t_min, sky_intensity, n0, n1, n2, cnt);
@@ -1774,6 +1833,18 @@ int launch_path_walk(const LaunchCfg&, const DevScene&, const rt_camera&, const 
     hipLaunchKernelGGL((k_path<SWP, TIE>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
 #define RT_PATH(SWP) do { if (sc.tie) RT_PATH_T(SWP, true); else RT_PATH_T(SWP, false); } while (0)
+// (scenes whose only scattering kind is Lambertian: shaded right after the closest hit)
+#define RT_PATH_F(SWP, TIE, FUSE)                                                                       \
+    hipLaunchKernelGGL((k_path<SWP, TIE, FUSE>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
+                       (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
+#define RT_PATH_FUSED(SWP) do { if (sc.fuse == 2u) { if (sc.tie) RT_PATH_F(SWP, true, FUSE_ANY); else RT_PATH_F(SWP, false, FUSE_ANY); } \
+                                else if (sc.tie) RT_PATH_F(SWP, true, RT_MAT_LAMBERT); else RT_PATH_F(SWP, false, RT_MAT_LAMBERT); } while (0)
+#define RT_PATH_LDS_F(SWP, TIE, FUSE)                                                                   \
+    hipLaunchKernelGGL((k_path<SWP, TIE, FUSE>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
+                       bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
+                       sky_intensity RT_STAMP_ARG)
+#define RT_PATH_LDS_FUSED(SWP) do { if (sc.fuse == 2u) { if (sc.tie) RT_PATH_LDS_F(SWP, true, FUSE_ANY); else RT_PATH_LDS_F(SWP, false, FUSE_ANY); } \
+                                    else if (sc.tie) RT_PATH_LDS_F(SWP, true, RT_MAT_LAMBERT); else RT_PATH_LDS_F(SWP, false, RT_MAT_LAMBERT); } while (0)
 #define RT_PATH_LDS_T(SWP, TIE)                                                                         \
     hipLaunchKernelGGL((k_path<SWP, TIE>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
                        bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
@@ -1851,7 +1922,9 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
     }
     if (sc.lds_walk && !sc.ordered && !sc.octant) {
         const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
-        if (sc.refill) RT_PATH_LDS(6); else RT_PATH_LDS(4);
+        if (sc.refill) RT_PATH_LDS(6);
+        else if (sc.fuse) RT_PATH_LDS_FUSED(4);
+        else RT_PATH_LDS(4);
         return check_launch();
     }
     if (sc.split_top && sc.refill && !sc.ordered && !sc.octant && !sc.tie) {
@@ -1862,6 +1935,7 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
     if (sc.octant) { if (sc.refill) RT_PATH_T(8, true); else RT_PATH_T(7, true); }
     else if (sc.ordered) RT_PATH_T(3, true);
     else if (sc.refill) RT_PATH(5);
+    else if (sc.fuse) RT_PATH_FUSED(0);
     else RT_PATH(0);
     return check_launch();
 }
@@ -1944,7 +2018,9 @@ int launch_path(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& cam, 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.has_spheres) RT_PATH(2); else RT_PATH(1);
+    if (sc.has_spheres) { if (sc.fuse) RT_PATH_FUSED(2); else RT_PATH(2); }
+    else if (sc.fuse) RT_PATH_FUSED(1);
+    else RT_PATH(1);
     return check_launch();
 }
 

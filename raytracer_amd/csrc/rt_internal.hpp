@@ -217,6 +217,8 @@ struct DevScene {
     const void* prim_geo;     // float4[n_prims], by rank
     const uint32_t* prim_meta; // by rank
     const uint32_t* prim_order;   // rank -> primitive id
+    uint32_t fuse;            // the fused kernel shades a ray right after its closest hit instead of queueing it for a
+                              // shade pass: 1 (Lambertian is the scene's only scattering kind), 2 (every kind), 0: off
     uint32_t tie;             // 1: the walk does not visit in the reference's order (another tree, or nearer child
                               // first): exact ties in t are resolved by primitive key
     const void* materials;    // float4[2 * n_mats]

@@ -2,7 +2,7 @@
 # Kernel-trace profiles of the default benchmark command (run on the GPU box from the repository
 # root):  bash tools/profile_headline.sh <out dir>
 # rocprofv3 --kernel-trace --stats of `python3 bench.py --no-cpu` and of its --staged form; the
-# average duration of k_path<1> there is what bench.py's avg_launch_ms must agree with.  (The PMC
+# average duration of the per-batch kernel k_path there is what bench.py's avg_launch_ms must agree with.  (The PMC
 # passes of every workload, the headline included, are tools/profile_workloads.sh.)
 set -e
 out=${1:-gpurun_out/headline}
