@@ -1184,7 +1184,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         }
         if (forms.size() == 1) { set_form(forms[0]); forms.clear(); }
         size_t best = 0;
-        float best_ms = 0.0f;
+        double best_ms = 0.0;              // per Mi paths
         // an error return from the probe leaves the scene on the form it had
         struct Restore {
             rt_scene* s;
@@ -1209,17 +1209,32 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             // Small scenes (sweep against the walk out of LDS) are cheap and the forms lie close
             // together, so the probe is a whole batch of the frame, cut into the segments the form
             // really gets (the sweep fills its groups of 128 rays worse from short segments).  Big
-            // scenes: at most 4 Mi paths, in segments as long as the real batches' (what the refill
-            // draws on) but not over 512, so that the probe still spreads over every wave slot.
-            const size_t nt = whole_batch ? tiles_per_batch : std::min<size_t>(tiles_per_batch, 4096);
+            // scenes: tiles spread evenly over the whole rectangle (the first tiles of a frame are often
+            // sky), in segments as long as the real batches' -- the refilled forms live on long segments
+            // (cornell_box.obj at 256 spp: the wide walk is 1.4x the refilled binary walk in the frame
+            // and level with it on segments of 512 paths) -- and two of them for every wave slot of the
+            // chip, so that waves follow waves as in the frame: at least 4 Mi paths, at most the batch.
+            // The forms' probes differ in size; they are compared by time per path.
+            const size_t batch_paths = tiles_per_batch * 64 * (size_t)samples_per_batch;
+            const uint32_t seg_len_real = seg_len_for(batch_paths, form_target(s->dev));
+            const size_t probe_paths = std::min(batch_paths, std::max<size_t>((size_t)4 << 20, (size_t)seg_len_real * 2 * ctx->wave_target_sweep));
+            const uint32_t probe_samples = (uint32_t)std::min<size_t>(samples_per_batch, 16);
+            size_t nt = whole_batch ? tiles_per_batch
+                                    : std::min<size_t>(tiles_per_batch, std::max<size_t>(1, probe_paths / 64 / probe_samples));
+            if (!whole_batch) {          // every stride-th tile of the rectangle; a stride that does not walk down one tile column
+                auto gcd = [](size_t a, size_t b) { while (b) { const size_t r = a % b; a = b; b = r; } return a; };
+                size_t stride = (n_tiles + nt - 1) / nt;
+                while (stride > 1 && gcd(stride, tiles_x) != 1) stride++;
+                nt = std::max<size_t>(1, n_tiles / stride);
+                g.tile_stride = (uint32_t)stride;
+            }
             g.n_pix_slots = (uint32_t)(nt * 64);
             g.sample_base = p->sample_begin;
             g.n_samples = whole_batch ? samples_per_batch
-                                      : (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, ((size_t)4 << 20) / (nt * 64)));
+                                      : (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, probe_paths / (nt * 64)));
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
-            g.seg_len = seg_len_for(tiles_per_batch * 64 * (size_t)samples_per_batch, form_target(s->dev));
-            if (!whole_batch) g.seg_len = std::min(512u, g.seg_len);
+            g.seg_len = seg_len_real;
             g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
             // (a whole-batch probe runs the way the frame will: one batch on each pipeline at once --
             // the sweep gains more from a second kernel in flight than the walk out of LDS does)
@@ -1257,18 +1272,20 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 HIP_TRY(hipEventRecord(ctx->ev_end, pp.stream));
             }
             HIP_TRY(hipStreamSynchronize(pp.stream));
-            float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+            float ms_run = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms_run, ctx->ev_begin, ctx->ev_end));
+            const double ms = (double)ms_run * 1048576.0 / ((double)g.n_slots * probe_pipes);
             if (std::getenv("RT_AUTOTUNE_LOG"))       // the probe's timings on stderr
-                std::fprintf(stderr, "[rt probe] tree %d sweep %u wide %u refill %u prim_wait %u: %.3f ms (%u slots in %u segments, %d pipelines)\n",
-                             forms[f].tree, forms[f].sweep, forms[f].wide, forms[f].refill, forms[f].prim_wait, ms, g.n_slots, g.n_seg, probe_pipes);
+                std::fprintf(stderr, "[rt probe] tree %d sweep %u wide %u refill %u prim_wait %u: %.3f ms per Mi paths (%.3f ms, %u slots in %u segments, every %u. tile, %d pipelines)\n",
+                             forms[f].tree, forms[f].sweep, forms[f].wide, forms[f].refill, forms[f].prim_wait, ms, ms_run, g.n_slots, g.n_seg,
+                             g.tile_stride, probe_pipes);
             // The probe is one batch per pipeline, started together and drained to the end, and that flatters
             // the walk: in the frame itself batch follows batch and the sweep's long-lived waves (one per wave
             // slot) lose less to the drain than here.  Measured on the plane Cornell box, a 1/8 share of the
             // frame: probe 11.4 ms sweep against 10.8-11.4 ms walk, frame 37.6 ms against 40.8 ms.  A form that
             // is not a sweep therefore has to beat a sweep by a tenth to be taken (where the walks really win
             // -- objects scattered under a sky, the surface-area trees -- they win by 1.2-1.5x).
-            const float margin = (f > 0 && forms[best].sweep && !forms[f].sweep) ? 0.9f : 1.0f;
+            const double margin = (f > 0 && forms[best].sweep && !forms[f].sweep) ? 0.9 : 1.0;
             if (f == 0 || ms < best_ms * margin) { best = f; best_ms = ms; }
         }
         if (!forms.empty()) set_form(forms[best]);
