@@ -1161,9 +1161,13 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             // every form that reports the reference's hits, on every tree the scene has (the base tree first:
             // it keeps a draw)
             const int base = s->base_tree();
+            const bool fast_only = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && !s->trees[TREE_FAST].lds_walk &&
+                                   !std::getenv("RT_AUTO_ALL_TREES");
             for (int which : {base, 1 - base}) {
                 const SceneTree& t = s->trees[which];
                 if (!t.present) continue;
+                // (walked from memory the median-split trees have lost every timing by 1.2-2x: they are left out)
+                if (fast_only && which == TREE_REFERENCE) continue;
                 if (t.n_entries <= SWEEP_MAX_ENTRIES && s->dev.n_xforms == 0) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
                 if (t.lds_walk) forms.push_back(Form{which, 0u, pinned_refill ? s->env_refill : 0u, s->dev.prim_wait, 0u});
                 else if (pinned_refill) forms.push_back(Form{which, 0u, s->env_refill, s->dev.prim_wait, 0u});
@@ -1198,7 +1202,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
                 s->dev.tie = tie;
             }
         } restore{s, Form{s->cur, s->dev.sweep, s->dev.refill, s->dev.prim_wait, s->dev.wide}, s->dev.tie};
-        const bool whole_batch = s->trees[s->base_tree()].lds_walk;
+        const bool big_scene = !s->trees[s->base_tree()].lds_walk;
+        const int probe_passes = std::getenv("RT_PROBE_PASSES") ? std::max(1, std::atoi(std::getenv("RT_PROBE_PASSES"))) : 1;
+        for (int pass = 0; pass < probe_passes; pass++)
         for (size_t f = 0; f < forms.size(); f++) {
             set_form(forms[f]);
             BatchGeom g;
@@ -1206,39 +1212,41 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             g.x0 = p->x0; g.y0 = p->y0; g.x1 = p->x1; g.y1 = p->y1;
             g.tiles_x = tiles_x;
             g.tile_base = 0;
-            // Small scenes (sweep against the walk out of LDS) are cheap and the forms lie close
-            // together, so the probe is a whole batch of the frame, cut into the segments the form
-            // really gets (the sweep fills its groups of 128 rays worse from short segments).  Big
-            // scenes: tiles spread evenly over the whole rectangle (the first tiles of a frame are often
-            // sky), in segments as long as the real batches' -- the refilled forms live on long segments
-            // (cornell_box.obj at 256 spp: the wide walk is 1.4x the refilled binary walk in the frame
-            // and level with it on segments of 512 paths) -- and two of them for every wave slot of the
-            // chip, so that waves follow waves as in the frame: at least 4 Mi paths, at most the batch.
-            // The forms' probes differ in size; they are compared by time per path.
+            // The probe is the frame's own first batch, cut into the segments the form really gets, on
+            // each pipeline the frame will use (the second pipeline takes the next samples of the same
+            // tiles, as in the frame).  Anything smaller misleads: the sweep fills its groups of 128
+            // rays worse from short segments; the refilled forms live on long segments; and a launch
+            // with fewer waves than the frame's has another balance between its steady state and its
+            // drain (cornell_box.obj at 256 spp, one batch of 64 Mi paths in 32 Ki segments: wide walk
+            // 36 ms, refilled binary walk 51 ms; half the segments: 27 ms against 28 ms).  When a batch
+            // holds only a part of the frame's tiles (beyond 64 Mi pixels) it is probed on runs of
+            // consecutive tiles spread evenly over the rectangle: the first tiles of a frame are
+            // often sky.
             const size_t batch_paths = tiles_per_batch * 64 * (size_t)samples_per_batch;
-            const uint32_t seg_len_real = seg_len_for(batch_paths, form_target(s->dev));
-            const size_t probe_paths = std::min(batch_paths, std::max<size_t>((size_t)4 << 20, (size_t)seg_len_real * 2 * ctx->wave_target_sweep));
-            const uint32_t probe_samples = (uint32_t)std::min<size_t>(samples_per_batch, 16);
-            size_t nt = whole_batch ? tiles_per_batch
-                                    : std::min<size_t>(tiles_per_batch, std::max<size_t>(1, probe_paths / 64 / probe_samples));
-            if (!whole_batch) {          // every stride-th tile of the rectangle; a stride that does not walk down one tile column
-                auto gcd = [](size_t a, size_t b) { while (b) { const size_t r = a % b; a = b; b = r; } return a; };
-                size_t stride = (n_tiles + nt - 1) / nt;
-                while (stride > 1 && gcd(stride, tiles_x) != 1) stride++;
-                nt = std::max<size_t>(1, n_tiles / stride);
-                g.tile_stride = (uint32_t)stride;
-            }
+            const size_t nt = tiles_per_batch;
+            const int probe_pipes = std::max(1, std::min(n_pipes, 2));
+            uint32_t pipe_tile_base[2] = {0, 0}, pipe_sample_base[2] = {p->sample_begin, p->sample_begin};
+            if (n_samples >= 2 * samples_per_batch) pipe_sample_base[1] += samples_per_batch;
             g.n_pix_slots = (uint32_t)(nt * 64);
-            g.sample_base = p->sample_begin;
-            g.n_samples = whole_batch ? samples_per_batch
-                                      : (uint32_t)std::min<size_t>(samples_per_batch, std::max<size_t>(1, probe_paths / (nt * 64)));
+            g.n_samples = samples_per_batch;
             g.n_slots = g.n_pix_slots * g.n_samples;
             g.band_tile_rows = band_tile_rows; g.band_count = band_count; g.band_index = p->band_index;
-            g.seg_len = seg_len_real;
+            g.seg_len = seg_len_for(batch_paths, form_target(s->dev));
             g.n_seg = (g.n_slots + g.seg_len - 1) / g.seg_len;
-            // (a whole-batch probe runs the way the frame will: one batch on each pipeline at once --
-            // the sweep gains more from a second kernel in flight than the walk out of LDS does)
-            const int probe_pipes = whole_batch ? std::max(1, std::min(n_pipes, 2)) : 1;
+            if (nt < n_tiles) {
+                uint32_t shift = 6;                                     // runs of 64 tiles, or a segment's tiles if that is more
+                while (((size_t)64 << shift) < g.seg_len) shift++;
+                const size_t run = (size_t)1 << shift, n_runs = nt / run;
+                if (n_runs >= 1 && nt % run == 0 && n_tiles / run >= 2 * n_runs) {
+                    size_t stride = (n_tiles / run) / n_runs;
+                    // (runs that all start in the same tile column would cover a stripe of the frame)
+                    if (run % tiles_x != 0 && (stride * run) % tiles_x == 0) stride--;
+                    if (stride > 1) {
+                        g.tile_run_shift = shift;
+                        g.tile_gap = (uint32_t)((stride - 1) * run);
+                    }
+                }
+            }
             RenderBuffers rbs[2];
             for (int k = 0; k < probe_pipes; k++) {
                 Pipe& pk = ctx->pipes[k];
@@ -1257,14 +1265,22 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             }
             Pipe& pp = ctx->pipes[0];
             for (int rep = 0; rep < 2; rep++) {            // the second run is the timed one
+                BatchGeom gr = g;
+                if (rep == 0 && big_scene) {               // (a big scene's first run only warms code, TLBs and the top of the tree)
+                    gr.n_seg = std::max<uint32_t>(1, g.n_seg / 8);
+                    gr.n_slots = std::min<uint32_t>(g.n_slots, gr.n_seg * g.seg_len);
+                }
                 HIP_TRY(hipEventRecord(ctx->ev_begin, pp.stream));
                 for (int k = 1; k < probe_pipes; k++) {
                     HIP_TRY(hipEventRecord(ctx->ev_fork, pp.stream));
                     HIP_TRY(hipStreamWaitEvent(ctx->pipes[k].stream, ctx->ev_fork, 0));
                 }
-                for (int k = 0; k < probe_pipes; k++)
-                    if (launch_path(ctx->cfg(k), s->dev, *cam, g, p->seed, rbs[k], p->max_bounces, p->t_min, p->sky_intensity))
+                for (int k = 0; k < probe_pipes; k++) {
+                    gr.tile_base = pipe_tile_base[k];
+                    gr.sample_base = pipe_sample_base[k];
+                    if (launch_path(ctx->cfg(k), s->dev, *cam, gr, p->seed, rbs[k], p->max_bounces, p->t_min, p->sky_intensity))
                         return fail(RT_ERR_DEVICE, "path kernel launch failed");
+                }
                 for (int k = 1; k < probe_pipes; k++) {
                     HIP_TRY(hipEventRecord(ctx->pipes[k].joined, ctx->pipes[k].stream));
                     HIP_TRY(hipStreamWaitEvent(pp.stream, ctx->pipes[k].joined, 0));
@@ -1276,9 +1292,9 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             HIP_TRY(hipEventElapsedTime(&ms_run, ctx->ev_begin, ctx->ev_end));
             const double ms = (double)ms_run * 1048576.0 / ((double)g.n_slots * probe_pipes);
             if (std::getenv("RT_AUTOTUNE_LOG"))       // the probe's timings on stderr
-                std::fprintf(stderr, "[rt probe] tree %d sweep %u wide %u refill %u prim_wait %u: %.3f ms per Mi paths (%.3f ms, %u slots in %u segments, every %u. tile, %d pipelines)\n",
+                std::fprintf(stderr, "[rt probe] tree %d sweep %u wide %u refill %u prim_wait %u: %.3f ms per Mi paths (%.3f ms, %u slots in %u segments, runs of %u tiles %u apart, %d pipelines)\n",
                              forms[f].tree, forms[f].sweep, forms[f].wide, forms[f].refill, forms[f].prim_wait, ms, ms_run, g.n_slots, g.n_seg,
-                             g.tile_stride, probe_pipes);
+                             1u << g.tile_run_shift, g.tile_gap + (1u << g.tile_run_shift), probe_pipes);
             // The probe is one batch per pipeline, started together and drained to the end, and that flatters
             // the walk: in the frame itself batch follows batch and the sweep's long-lived waves (one per wave
             // slot) lose less to the drain than here.  Measured on the plane Cornell box, a 1/8 share of the

@@ -1025,7 +1025,7 @@ __device__ __forceinline__ void sample_ball(float u1, float u2, float u3, float&
 
 // decode a pixel slot of the batch (8x8 tiles, row-major inside a tile)
 __device__ __forceinline__ bool slot_pixel(const BatchGeom& g, uint32_t q, uint32_t& x, uint32_t& y) {
-    const uint32_t tile = g.tile_base + (q >> 6) * g.tile_stride, in = q & 63u;
+    const uint32_t i = q >> 6, in = q & 63u, tile = g.tile_base + i + (i >> g.tile_run_shift) * g.tile_gap;
     const uint32_t tx = tile % g.tiles_x;
     uint32_t ty = tile / g.tiles_x;                        // index among the owned tile rows
     if (g.band_count > 1u)

@@ -276,7 +276,9 @@ struct BatchGeom {
     uint32_t x0, y0, x1, y1;      // rectangle
     uint32_t tiles_x;             // 8x8 tiles per row of the rectangle
     uint32_t tile_base;           // first tile of this batch
-    uint32_t tile_stride = 1;     // tile of pixel slot q: tile_base + (q / 64) * tile_stride (a frame's batches: 1)
+    // tile of pixel slot q, with i = q / 64: tile_base + i + (i >> tile_run_shift) * tile_gap -- runs of
+    // consecutive tiles with gaps between them (a frame's batches: no gaps)
+    uint32_t tile_run_shift = 0, tile_gap = 0;
     uint32_t n_pix_slots;         // 64 * tiles in this batch
     uint32_t sample_base, n_samples;
     uint32_t n_slots;             // n_pix_slots * n_samples

@@ -55,8 +55,8 @@ def test_auto_keeps_the_reference_frame(rt, ob, ctx, name, capfd, monkeypatch):
 
 
 def test_auto_on_a_scene_walked_from_memory(rt, ob, ctx, capfd, monkeypatch):
-    """Trees that do not fit LDS: the candidates are the plain and the refilled walk on both trees and
-    the wide walk over the surface-area trees."""
+    """Trees that do not fit LDS: the candidates are the plain and the refilled walk and the wide walk
+    over the surface-area trees (RT_AUTO_ALL_TREES=1 adds the two walks over the reference's trees)."""
     monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
     mats, objects, _ = random_scene(ob, 19, n_spheres=60, n_meshes=3, tris_per_mesh=4000, extent=8.0)
     osc = ob.Scene.from_description(mats, objects, ob.ROOT_BVH)
@@ -71,11 +71,19 @@ def test_auto_on_a_scene_walked_from_memory(rt, ob, ctx, capfd, monkeypatch):
     with capfd.disabled():
         print(f"\nrandom scene: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree: "
               + "; ".join(l.split("] ")[1].split(" (")[0] for l in probes))
-    assert len(probes) == 5 and sum("wide 1" in l for l in probes) == 1
+    assert len(probes) == 3 and sum("wide 1" in l for l in probes) == 1 and all("tree 1" in l for l in probes)
     assert st["rays_traced"] == st_want["rays_traced"] and np.array_equal(img.view(np.uint32), want.view(np.uint32))
     rays = random_rays(ob, 5, 150000, -10.0, 10.0)
     oracle, _ = osc.trace(rays)
     assert_hits_equal(sc.trace(rays), oracle)
+    sc.close()
+    monkeypatch.setenv("RT_AUTO_ALL_TREES", "1")
+    sc = mirror(rt, ctx, osc)
+    capfd.readouterr()
+    img, st = sc.render(cam, p)
+    probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    assert len(probes) == 5 and sum("tree 0" in l for l in probes) == 2
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
     sc.close()
 
 
