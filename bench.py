@@ -487,7 +487,7 @@ def main():
             # what the library reports about its GPUs and its reduce (the last timed step)
             n_show = min(world, 16)
             out["multi_gpu"] = {
-                "rccl_ranks": st["rccl_ranks"], "reduce": "rccl" if st["reduce_mode"] == rt.REDUCE_RCCL else "ordered (copied to the root, added in rank order)",
+                "rccl_ranks": st["rccl_ranks"], "rccl_version": rt.lib.rt_rccl_version(), "reduce": "rccl" if st["reduce_mode"] == rt.REDUCE_RCCL else "ordered (copied to the root, added in rank order)",
                 "reduce_ms": round(st["ms_reduce"], 3),
                 "device_ms_render": [round(v, 3) for v in st["device_ms_render"][:n_show]],
                 "ms_render_min": round(st["ms_render_min"], 3), "ms_render_max": round(st["ms_render"], 3),

@@ -396,6 +396,10 @@ int rt_render_multi_device(rt_scene* scene, const rt_camera* cam, const rt_rende
  * contexts created afterwards. */
 enum { RT_REDUCE_RCCL = 0, RT_REDUCE_ORDERED = 1 };
 int rt_context_set_reduce(rt_context* ctx, int mode);
+/* The version of the RCCL library this process resolved (ncclGetVersion: major * 10000 + minor * 100
+ * + patch; 0 if the call fails).  The library is linked against librccl.so.1 by name: a process that
+ * loaded PyTorch first runs on the RCCL bundled with it, any other on the system's. */
+int rt_rccl_version(void);
 
 /* ---- tonemap: main.rs:369-373 + rgb_to_u32 (math.rs:112-116) --------------------------- */
 int rt_tonemap(rt_context* ctx, const float* accum_rgb, uint32_t spp, uint32_t* out_0rgb, size_t npix);

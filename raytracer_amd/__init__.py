@@ -96,6 +96,7 @@ def _load():
         "rt_context_create_multi": (i32, [i32, C.POINTER(i32), pp]),
         "rt_context_num_devices": (i32, [vp]),
         "rt_context_set_reduce": (i32, [vp, i32]),
+        "rt_rccl_version": (i32, []),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, []),
         "rt_context_stream": (vp, [vp]),
@@ -169,7 +170,7 @@ def _load():
 
 lib = _load()
 ABI_SYMBOLS = [
-    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_set_reduce", "rt_context_destroy", "rt_last_error",
+    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_set_reduce", "rt_rccl_version", "rt_context_destroy", "rt_last_error",
     "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",

@@ -369,6 +369,11 @@ int rt_context_set_reduce(rt_context* ctx, int mode) {
     return RT_OK;
 }
 
+int rt_rccl_version(void) {
+    int v = 0;
+    return ncclGetVersion(&v) == ncclSuccess ? v : 0;
+}
+
 void rt_context_destroy(rt_context* ctx) {
     if (!ctx) return;
     if (ctx->destroyed) return;

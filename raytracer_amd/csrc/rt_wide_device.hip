@@ -84,29 +84,48 @@ k_reach(const float4* __restrict__ ent, uint32_t n_entries, uint32_t* __restrict
 }
 
 // primitive entries -> compact list (entry index | BOXLESS); bounds of the box centres (as ordered
-// unsigneds: [0..2] min, [3..5] max).  The list is numbered per wave: one ballot, one atomic of the
-// wave's count, the lanes' places by prefix (one atomic per PRIMITIVE on the single counter took 18 of
-// the build's 22 ms of kernel time on 10 M triangles).  `cover` is null when no primitive can be box-less.
+// unsigneds: [0..2] min, [3..5] max).  A workgroup takes a contiguous stretch of the entry array and
+// passes over it twice: it counts its primitives, reserves their places with ONE atomic, then writes
+// them, every wave numbering its own by ballot and prefix.  (Atomics of all waves on one counter are
+// served one after the other, about 57 ns apiece on this part: one per wave and trip -- 312 k for
+// 10 M triangles, which is also what the compiler makes of one per lane -- took 18 of the build's
+// 22 ms of kernel time.)  `cover` is null when no primitive can be box-less.
 __global__ void __launch_bounds__(WB)
-k_collect(const float4* __restrict__ ent, uint32_t n_entries, const uint32_t* __restrict__ cover,
+k_collect(const float4* __restrict__ ent, uint32_t n_entries, uint32_t per_block, const uint32_t* __restrict__ cover,
           uint32_t* __restrict__ prim_entry, Counters* cnt, uint32_t* __restrict__ bounds) {
+    __shared__ uint32_t wave_count[WB / 64], block_base, red[6][WB / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t begin = blockIdx.x * per_block, end = min(n_entries, begin + per_block);   // (per_block is a multiple of WB)
+    uint32_t mine = 0;
+    for (uint32_t base = begin; base < end; base += WB) {        // (wave-uniform trip count)
+        const uint32_t e = base + threadIdx.x;
+        uint32_t tag = TAG_END;
+        if (e < end) tag = __float_as_uint(ent[4 * (size_t)e].w) >> TAG_SHIFT;
+        mine += (uint32_t)__popcll(__ballot(tag == TAG_TRI || tag == TAG_SPH));
+    }
+    if (lane == 0) wave_count[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < WB / 64; w++) total += wave_count[w];
+        block_base = total ? atomicAdd(&cnt->n_prims, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = block_base;
+    for (uint32_t w = 0; w < wave; w++) at += wave_count[w];
     uint32_t mn[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, mx[3] = {0u, 0u, 0u};
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = blockIdx.x * WB; base < n_entries; base += gridDim.x * WB) {     // (wave-uniform trip count)
+    for (uint32_t base = begin; base < end; base += WB) {
         const uint32_t e = base + threadIdx.x;
         float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (e < n_entries) a = ent[4 * (size_t)e];
+        if (e < end) a = ent[4 * (size_t)e];
         const uint32_t tag = __float_as_uint(a.w) >> TAG_SHIFT;
-        const bool is_prim = e < n_entries && (tag == TAG_TRI || tag == TAG_SPH);
+        const bool is_prim = e < end && (tag == TAG_TRI || tag == TAG_SPH);
         const unsigned long long m = __ballot(is_prim);
-        if (m == 0ull) continue;
-        uint32_t first = 0;
-        if (lane == 0) first = atomicAdd(&cnt->n_prims, (uint32_t)__popcll(m));
-        first = (uint32_t)__shfl((int)first, 0);
+        const uint32_t place = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        at += (uint32_t)__popcll(m);
         if (!is_prim) continue;
-        const uint32_t at = first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const bool boxless = cover != nullptr && cover[e] <= e;
-        prim_entry[at] = e | (boxless ? BOXLESS : 0u);
+        prim_entry[place] = e | (boxless ? BOXLESS : 0u);
         float lo[3], hi[3];
         prim_box(a, ent[4 * (size_t)e + 1], ent[4 * (size_t)e + 2], lo, hi);
         for (int k = 0; k < 3; k++) {
@@ -115,16 +134,20 @@ k_collect(const float4* __restrict__ ent, uint32_t n_entries, const uint32_t* __
             mx[k] = max(mx[k], c);
         }
     }
-    // (every lane of the wave is back together here: one pair of atomics per wave and axis)
+    // (every lane is back together here: one pair of atomics per workgroup and axis)
     for (int k = 0; k < 3; k++) {
         for (int off = 32; off > 0; off >>= 1) {
             mn[k] = min(mn[k], (uint32_t)__shfl_xor((int)mn[k], off));
             mx[k] = max(mx[k], (uint32_t)__shfl_xor((int)mx[k], off));
         }
-        if (lane == 0) {
-            atomicMin(&bounds[k], mn[k]);
-            atomicMax(&bounds[3 + k], mx[k]);
-        }
+        if (lane == 0) { red[k][wave] = mn[k]; red[3 + k][wave] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const uint32_t k = threadIdx.x;
+        uint32_t v = red[k][0];
+        for (uint32_t w = 1; w < WB / 64; w++) v = k < 3 ? min(v, red[k][w]) : max(v, red[k][w]);
+        if (k < 3) atomicMin(&bounds[k], v); else atomicMax(&bounds[k], v);
     }
 }
 
@@ -349,7 +372,12 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
         HIP_OK(tmp.get(&scan_tmp, scan_bytes));
         HIP_OK(hipcub::DeviceScan::ExclusiveScan(scan_tmp, scan_bytes, reach, cover, hipcub::Max(), 0u, (int)n_entries, st));
     }
-    if (n_entries) hipLaunchKernelGGL(k_collect, dim3(grid(n_entries)), dim3(WB), 0, st, ent, n_entries, (const uint32_t*)cover, prim_entry, cnt, bounds);
+    if (n_entries) {
+        // contiguous stretches of the entry array, about eight workgroups per CU
+        const uint32_t per_block = (uint32_t)std::max<size_t>(WB, (((size_t)n_entries + 2047) / 2048 + WB - 1) / WB * WB);
+        const uint32_t blocks = (n_entries + per_block - 1) / per_block;
+        hipLaunchKernelGGL(k_collect, dim3(blocks), dim3(WB), 0, st, ent, n_entries, per_block, (const uint32_t*)cover, prim_entry, cnt, bounds);
+    }
     Counters h{};
     HIP_OK(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));

@@ -94,6 +94,7 @@ extern "C" {
     pub fn rt_context_create_multi(n_dev: c_int, dev_ids: *const c_int, out: *mut *mut rt_context) -> c_int;
     pub fn rt_context_num_devices(ctx: *const rt_context) -> c_int;
     pub fn rt_context_set_reduce(ctx: *mut rt_context, mode: c_int) -> c_int;
+    pub fn rt_rccl_version() -> c_int;
     pub fn rt_context_destroy(ctx: *mut rt_context);
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_context_stream(ctx: *mut rt_context) -> *mut c_void;
