@@ -32,6 +32,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -475,6 +477,9 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
     out.n_prims = n;
     out.depth = depth;
     out.node_words = stride;
+    if (std::getenv("RT_BUILD_LOG"))          // the tree's size on stderr
+        std::fprintf(stderr, "[rt wide build, device] %u primitives, %u levels, %u node slots of %u bytes: %.1f MB of nodes, %.1f MB of primitive records\n",
+                     n, depth, slots, stride * 4u, out.nodes_bytes / 1e6, out.prims_bytes / 1e6);
     return 0;
 }
 
