@@ -228,12 +228,15 @@ int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CA
  * trees); they differ in speed only.  PER_LANE: every lane follows its own cursor (any scene
  * size).  SWEEP: the wave sweeps the entry array once with scalar fetches (small scenes).
  * AUTO takes the fastest form whose hits are the reference's: the first render of the scene times
- * the candidates on a probe batch of its own frame and keeps the winner (rt_stats.kernel_form and
- * rt_stats.tree say which).  Candidates: on the reference's trees the sweep (up to 192 entries)
- * and the per-lane walk (out of LDS when the trees fit, else from memory, plain or with idle lanes
- * refilled); for a scene of RT_BUILD_AUTO the same forms on the surface-area trees and, when those
- * do not fit LDS, the wide walk over them.  Every candidate reports the reference's primitive and
+ * the candidates on the first batch of its own frame (output discarded) and keeps the winner
+ * (rt_stats.kernel_form and rt_stats.tree say which).  Candidates: on the reference's trees the
+ * sweep (up to 192 entries) and the per-lane walk (out of LDS when the trees fit, else from memory,
+ * plain or with idle lanes refilled); for a scene of RT_BUILD_AUTO the same forms on the
+ * surface-area trees and, when those do not fit LDS, the wide walk over them (such a scene is then
+ * timed on its surface-area trees only).  Every candidate reports the reference's primitive and
  * t on every ray (ties in t by primitive key), so the frame does not depend on the choice.
+ * Environment: RT_AUTOTUNE_LOG=1 prints the timings on stderr, RT_NO_AUTOTUNE=1 keeps the first
+ * candidate, RT_AUTO_ALL_TREES=1 times the reference's trees as well when they are walked from memory.
  * ORDERED has no counterpart in the reference: the same trees, the same box and primitive tests,
  * but at every box the child nearer along the ray is visited first (per-lane stack), so the
  * narrowed t_max culls far more boxes; ties in t are resolved by primitive key.  Fails with
