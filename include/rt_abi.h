@@ -227,16 +227,21 @@ int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CA
  * (shape.rs:142-158, 292-324) and give bit-identical hits by construction (on the reference's
  * trees); they differ in speed only.  PER_LANE: every lane follows its own cursor (any scene
  * size).  SWEEP: the wave sweeps the entry array once with scalar fetches (small scenes).
- * AUTO takes the fastest form whose hits are the reference's: the first render of the scene times
- * the candidates on the first batch of its own frame (output discarded) and keeps the winner
- * (rt_stats.kernel_form and rt_stats.tree say which).  Candidates: on the reference's trees the
- * sweep (up to 192 entries) and the per-lane walk (out of LDS when the trees fit, else from memory,
- * plain or with idle lanes refilled); for a scene of RT_BUILD_AUTO the same forms on the
- * surface-area trees and, when those do not fit LDS, the wide walk over them (such a scene is then
- * timed on its surface-area trees only).  Every candidate reports the reference's primitive and
- * t on every ray (ties in t by primitive key), so the frame does not depend on the choice.
- * Environment: RT_AUTOTUNE_LOG=1 prints the timings on stderr, RT_NO_AUTOTUNE=1 keeps the first
- * candidate, RT_AUTO_ALL_TREES=1 times the reference's trees as well when they are walked from memory.
+ * AUTO takes the fastest form whose hits are the reference's (rt_stats.kernel_form and
+ * rt_stats.tree say which).  Every form reports the reference's primitive and t on every ray (ties
+ * in t by primitive key), so the frame does not depend on the choice.  On the reference's trees the
+ * forms are the sweep (up to 192 entries) and the per-lane walk (out of LDS when the trees fit, else
+ * from memory, plain or with idle lanes refilled); a scene of RT_BUILD_AUTO has the same forms on
+ * its surface-area trees and, when those do not fit LDS, the wide walk over them.  What is decided
+ * by rule (from measurements on every workload): the surface-area trees where the scene has them,
+ * and the wide walk where it applies.  What is decided by timing, on the first render whose first
+ * batch has 8 Mi paths or more (that batch, once per candidate, output discarded): sweep against
+ * walk out of LDS for scenes of up to 192 entries, plain against refilled walk for scenes walked
+ * from memory without a wide tree.  A smaller frame runs on the likelier form and leaves the
+ * timing to a later one.
+ * Environment: RT_AUTOTUNE_LOG=1 prints the timings on stderr, RT_NO_AUTOTUNE=1 keeps the scene's
+ * first form, RT_AUTO_PROBE_ALL=1 times every form on either tree, RT_PROBE_ANY_SIZE=1 times on
+ * frames of any size.
  * ORDERED has no counterpart in the reference: the same trees, the same box and primitive tests,
  * but at every box the child nearer along the ray is visited first (per-lane stack), so the
  * narrowed t_max culls far more boxes; ties in t are resolved by primitive key.  Fails with

@@ -1162,34 +1162,57 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         std::vector<Form> forms;
         const uint32_t wait_mem = s->env_prim_wait ? s->env_prim_wait : 8u, wait_refill = s->env_prim_wait ? s->env_prim_wait : 16u;
         const bool pinned_refill = std::getenv("RT_REFILL") != nullptr;
+        // RT_AUTO_PROBE_ALL=1: time every form on every tree (what the rules below are derived from)
+        const bool probe_all = std::getenv("RT_AUTO_PROBE_ALL") != nullptr;
         if (s->traversal == RT_TRAVERSAL_AUTO) {
-            // every form that reports the reference's hits, on every tree the scene has (the base tree first:
-            // it keeps a draw)
+            // The forms that report the reference's hits, on the trees the scene has (the base tree first: it
+            // keeps a draw).  A scene with a surface-area tree is timed on that tree only: on every workload
+            // and form measured it beat the median-split tree, by 1.07-2x.
             const int base = s->base_tree();
-            const bool fast_only = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && !s->trees[TREE_FAST].lds_walk &&
-                                   !std::getenv("RT_AUTO_ALL_TREES");
+            const bool fast = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present;
             for (int which : {base, 1 - base}) {
                 const SceneTree& t = s->trees[which];
                 if (!t.present) continue;
-                // (walked from memory the median-split trees have lost every timing by 1.2-2x: they are left out)
-                if (fast_only && which == TREE_REFERENCE) continue;
+                if (fast && which == TREE_REFERENCE && !probe_all) continue;
                 if (t.n_entries <= SWEEP_MAX_ENTRIES && s->dev.n_xforms == 0) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
                 if (t.lds_walk) forms.push_back(Form{which, 0u, pinned_refill ? s->env_refill : 0u, s->dev.prim_wait, 0u});
                 else if (pinned_refill) forms.push_back(Form{which, 0u, s->env_refill, s->dev.prim_wait, 0u});
                 else { forms.push_back(Form{which, 0u, 0u, wait_mem, 0u}); forms.push_back(Form{which, 0u, 16u, wait_refill, 0u}); }
             }
-            // the wide walk over the surface-area trees, for scenes that are walked from memory
-            if (s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && !s->trees[TREE_FAST].lds_walk &&
-                s->dev.n_xforms == 0 && !std::getenv("RT_AUTO_NO_WIDE")) {
+            // The wide walk over the surface-area trees, for scenes that are walked from memory.  Where it
+            // applies it is taken without a timing: on frames of real size it beat both binary walks on
+            // every such scene measured (cornell_box.obj 1.15-1.4x, 10 M triangles 3.6x), and a timing of
+            // three whole batches costs a one-frame job several times its frame.
+            if (fast && !s->trees[TREE_FAST].lds_walk && s->dev.n_xforms == 0 && !std::getenv("RT_AUTO_NO_WIDE")) {
                 const int was = s->cur;
                 bind_tree(s, TREE_FAST);
                 const int wrc = ensure_wide_tree(s);
                 bind_tree(s, was);
-                if (wrc == RT_OK) forms.push_back(Form{TREE_FAST, 0u, pinned_refill ? s->env_refill : 16u, s->dev.prim_wait, 1u});
-                else if (wrc != RT_ERR_UNSUPPORTED) return wrc;
+                if (wrc == RT_OK) {
+                    if (!probe_all) forms.clear();
+                    forms.push_back(Form{TREE_FAST, 0u, pinned_refill ? s->env_refill : 16u, s->dev.prim_wait, 1u});
+                } else if (wrc != RT_ERR_UNSUPPORTED) {
+                    return wrc;
+                }
             }
         } else if (!s->dev.sweep && (!s->dev.lds_walk || s->dev.octant) && !pinned_refill) {
             forms = {Form{s->cur, 0u, 0u, wait_mem, 0u}, Form{s->cur, 0u, 16u, wait_refill, 0u}};
+        }
+        // A timing needs a batch of the size real frames have: below 8 Mi paths the segments are too short
+        // for the refilled forms and too few for the sweep, and what wins there loses on a real frame (a
+        // 192 x 160 x 8 spp frame of a 12 k-triangle scene: plain walk 5.8, wide 7.6, refilled 9.4 ms per Mi
+        // paths; the reverse order from 16 Mi paths on).  Such a frame runs on the form that wins most
+        // often and the scene stays untimed until a larger frame comes.
+        bool timed = true;
+        if (forms.size() > 1 && tiles_per_batch * 64 * (size_t)samples_per_batch < ((size_t)8 << 20) && !std::getenv("RT_PROBE_ANY_SIZE")) {
+            size_t prior = 0;
+            for (size_t f = 0; f < forms.size(); f++) {
+                const bool lds = s->trees[forms[f].tree].lds_walk && !forms[f].sweep;
+                if (forms[f].wide || (lds && !forms[prior].wide) || (!forms[f].sweep && !forms[f].refill && forms[prior].sweep)) prior = f;
+            }
+            set_form(forms[prior]);
+            forms.clear();
+            timed = false;
         }
         if (forms.size() == 1) { set_form(forms[0]); forms.clear(); }
         size_t best = 0;
@@ -1311,7 +1334,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         }
         if (!forms.empty()) set_form(forms[best]);
         restore.keep = true;
-        s->auto_tuned = true;
+        s->auto_tuned = timed;
     }
     const uint32_t wave_target = form_target(s->dev);
     auto segments = [&](BatchGeom& g) {        // one wave per segment, a multiple of 64 slots long

@@ -1,8 +1,8 @@
 """RT_BUILD_AUTO + RT_TRAVERSAL_AUTO (the defaults): the scene holds the reference's trees and the
-surface-area trees, and its first render times every form of the closest-hit loop that reports the
-reference's hits -- on either tree, the wide walk included -- and keeps the fastest.  Whatever it
-keeps, the frame is the strict reference-order frame bit for bit and rt_trace reports the oracle's
-primitive and t on every ray."""
+surface-area trees, and its first render of a real size times the forms of the closest-hit loop that
+are contested (RT_AUTO_PROBE_ALL=1: every form on either tree, the wide walk included) and keeps the
+fastest.  Whatever it keeps, the frame is the strict reference-order frame bit for bit and rt_trace
+reports the oracle's primitive and t on every ray."""
 import numpy as np
 import pytest
 
@@ -23,6 +23,8 @@ def _strict_frame(rt, ctx, osc, cam, p):
 @pytest.mark.parametrize("name", ["cornell_box_plane.obj", "cornell_box.obj", "world1", "thing.obj"])
 def test_auto_keeps_the_reference_frame(rt, ob, ctx, name, capfd, monkeypatch):
     monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
+    monkeypatch.setenv("RT_AUTO_PROBE_ALL", "1")               # every form on either tree ...
+    monkeypatch.setenv("RT_PROBE_ANY_SIZE", "1")               # ... although the frame is a small one
     osc = {"world1": ob.Scene.world1, "thing.obj": lambda: ob.Scene.world2(asset("thing.obj"), 1)}.get(
         name, lambda: ob.Scene.cornell_box(asset(name)))()
     w, h, spp, depth = 256, 192, 32, 6
@@ -52,12 +54,26 @@ def test_auto_keeps_the_reference_frame(rt, ob, ctx, name, capfd, monkeypatch):
     _, st3 = sc.render(cam, p)
     assert rt.TREE_NAMES[st3["tree"]] == "reference"
     sc.close()
+    # Without the two switches: a frame this small (1.5 Mi paths) is not timed at all -- it runs on the
+    # form that wins most often on frames of real size, on the surface-area tree -- and the scene
+    # stays open to a timing by a later, larger frame.
+    monkeypatch.delenv("RT_AUTO_PROBE_ALL")
+    monkeypatch.delenv("RT_PROBE_ANY_SIZE")
+    sc = mirror(rt, ctx, osc)
+    capfd.readouterr()
+    img, st = sc.render(cam, p)
+    assert not [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
+    assert rt.TREE_NAMES[st["tree"]] == "sah"
+    assert rt.FORM_NAMES[st["kernel_form"]] == ("wide_refill" if name == "cornell_box.obj" else "walk_lds")
+    assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
+    sc.close()
 
 
 def test_auto_on_a_scene_walked_from_memory(rt, ob, ctx, capfd, monkeypatch):
-    """Trees that do not fit LDS: the candidates are the plain and the refilled walk and the wide walk
-    over the surface-area trees (RT_AUTO_ALL_TREES=1 adds the two walks over the reference's trees)."""
+    """Trees that do not fit LDS: the wide walk over the surface-area trees, taken without a timing;
+    RT_AUTO_PROBE_ALL=1 times it against the plain and the refilled walk on both trees."""
     monkeypatch.setenv("RT_AUTOTUNE_LOG", "1")
+    monkeypatch.setenv("RT_PROBE_ANY_SIZE", "1")
     mats, objects, _ = random_scene(ob, 19, n_spheres=60, n_meshes=3, tris_per_mesh=4000, extent=8.0)
     osc = ob.Scene.from_description(mats, objects, ob.ROOT_BVH)
     w, h, spp, depth = 192, 160, 8, 5
@@ -71,18 +87,21 @@ def test_auto_on_a_scene_walked_from_memory(rt, ob, ctx, capfd, monkeypatch):
     with capfd.disabled():
         print(f"\nrandom scene: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree: "
               + "; ".join(l.split("] ")[1].split(" (")[0] for l in probes))
-    assert len(probes) == 3 and sum("wide 1" in l for l in probes) == 1 and all("tree 1" in l for l in probes)
+    assert not probes and rt.FORM_NAMES[st["kernel_form"]] == "wide_refill" and rt.TREE_NAMES[st["tree"]] == "sah"
     assert st["rays_traced"] == st_want["rays_traced"] and np.array_equal(img.view(np.uint32), want.view(np.uint32))
     rays = random_rays(ob, 5, 150000, -10.0, 10.0)
     oracle, _ = osc.trace(rays)
     assert_hits_equal(sc.trace(rays), oracle)
     sc.close()
-    monkeypatch.setenv("RT_AUTO_ALL_TREES", "1")
+    monkeypatch.setenv("RT_AUTO_PROBE_ALL", "1")
     sc = mirror(rt, ctx, osc)
     capfd.readouterr()
     img, st = sc.render(cam, p)
     probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
-    assert len(probes) == 5 and sum("tree 0" in l for l in probes) == 2
+    with capfd.disabled():
+        print(f"random scene, every form: kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree: "
+              + "; ".join(l.split("] ")[1].split(" (")[0] for l in probes))
+    assert len(probes) == 5 and sum("tree 0" in l for l in probes) == 2 and sum("wide 1" in l for l in probes) == 1
     assert np.array_equal(img.view(np.uint32), want.view(np.uint32))
     sc.close()
 

@@ -65,8 +65,7 @@ def test_world2_with_translated_planes(rt, ob, ctx):
 def test_transformed_meshes_in_every_per_lane_form(rt, ob, ctx, scene, monkeypatch, capfd):
     """A scene with transformed meshes is traced by every per-lane form -- from memory or out of LDS,
     plain or with idle lanes refilled, on the reference's trees or the surface-area trees -- and the
-    frame is the staged launches' frame bit for bit whichever form runs; the defaults time them
-    all on the first render.  world2 with its two translated planes fits LDS and renders from there."""
+    frame is the staged launches' frame bit for bit whichever form runs.  world2 with its two translated planes fits LDS and renders from there."""
     if scene == "nested":
         mats, objects = _nested_description(ob, 83, True)
         cam = ((6.0, -7.0, 4.0), (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 50.0, 0.05, 9.0)
@@ -104,7 +103,8 @@ def test_transformed_meshes_in_every_per_lane_form(rt, ob, ctx, scene, monkeypat
     probes = [l for l in capfd.readouterr().err.splitlines() if l.startswith("[rt probe]")]
     with capfd.disabled():
         print(f"\n{scene}: {len(probes)} forms timed, kept {rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree")
-    assert len(probes) == 2 and "lds" in rt.FORM_NAMES[st["kernel_form"]]     # both scenes fit LDS: one form per tree
+    # both scenes fit LDS and have transformed meshes: one candidate, the walk out of LDS over the surface-area tree
+    assert not probes and rt.FORM_NAMES[st["kernel_form"]] == "walk_lds" and rt.TREE_NAMES[st["tree"]] == "sah"
     assert np.array_equal(img.view(np.uint32), staged.view(np.uint32))
     assert_hits_equal(sc.trace(rays), want)
     sc.close()
