@@ -190,42 +190,65 @@ __global__ void __launch_bounds__(WB)
 k_split(const unsigned long long* __restrict__ keys, const float4* __restrict__ ent, Run* __restrict__ runs, uint32_t off_in,
         uint32_t n_in, uint32_t off_out, Counters* cnt, uint4* __restrict__ heads, uint32_t slot_capacity,
         float4* __restrict__ prims) {
+    // (places in the three lists are handed out per workgroup -- a scan over its runs and one atomic
+    // per list -- because atomics of many waves on one counter are served one after the other)
+    typedef hipcub::BlockScan<uint32_t, WB> Scan;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ uint32_t list_base[3];
     const uint32_t i = blockIdx.x * WB + threadIdx.x;
-    if (i >= n_in) return;
-    const Run r = runs[off_in + i];
-    int shift = r.shift;
-    while (shift >= 0 && digit_of(keys[r.b], shift) == digit_of(keys[r.e - 1], shift)) shift -= 3;
-    uint32_t cb[9];
-    if (shift >= 0) {                          // children = runs of equal digit; the digit is the slot
-        cb[0] = r.b;
-        for (uint32_t d = 1; d < 8; d++) {     // first key whose digit is >= d (digits do not decrease along the run)
-            uint32_t lo = r.b, hi = r.e;
-            while (lo < hi) {
-                const uint32_t mid = lo + (hi - lo) / 2;
-                if (digit_of(keys[mid], shift) < d) lo = mid + 1; else hi = mid;
-            }
-            cb[d] = lo;
-        }
-        cb[8] = r.e;
-    } else {                                   // the same thirty bits throughout: equal parts
-        const uint32_t size = r.e - r.b, parts = size < 8u ? size : 8u;
-        for (uint32_t k = 0; k <= 8; k++) cb[k] = k <= parts ? r.b + (uint32_t)((unsigned long long)size * k / parts) : r.e;
-    }
+    const bool valid = i < n_in;
+    Run r{0u, 0u, 0u, 0};
+    int shift = -1;
+    uint32_t cb[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
     uint32_t imask = 0, lmask = 0;
-    for (uint32_t k = 0; k < 8; k++) {
-        const uint32_t size = cb[k + 1] - cb[k];
-        if (size == 1) lmask |= 1u << k;
-        else if (size > 1) imask |= 1u << k;
+    if (valid) {
+        r = runs[off_in + i];
+        shift = r.shift;
+        while (shift >= 0 && digit_of(keys[r.b], shift) == digit_of(keys[r.e - 1], shift)) shift -= 3;
+        if (shift >= 0) {                          // children = runs of equal digit; the digit is the slot
+            cb[0] = r.b;
+            for (uint32_t d = 1; d < 8; d++) {     // first key whose digit is >= d (digits do not decrease along the run)
+                uint32_t lo = r.b, hi = r.e;
+                while (lo < hi) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (digit_of(keys[mid], shift) < d) lo = mid + 1; else hi = mid;
+                }
+                cb[d] = lo;
+            }
+            cb[8] = r.e;
+        } else {                                   // the same thirty bits throughout: equal parts
+            const uint32_t size = r.e - r.b, parts = size < 8u ? size : 8u;
+            for (uint32_t k = 0; k <= 8; k++) cb[k] = k <= parts ? r.b + (uint32_t)((unsigned long long)size * k / parts) : r.e;
+        }
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t size = cb[k + 1] - cb[k];
+            if (size == 1) lmask |= 1u << k;
+            else if (size > 1) imask |= 1u << k;
+        }
     }
+    // the node children's slots: from the lowest to the highest occupied child slot
+    const uint32_t low = imask ? (uint32_t)__ffs((int)imask) - 1u : 0u;
+    const uint32_t span = imask ? 32u - (uint32_t)__clz((int)imask) - low : 0u;
+    uint32_t my_slot, my_prim, my_next, all_slots, all_prims, all_next;
+    Scan(scan_tmp).ExclusiveSum(span, my_slot, all_slots);
+    __syncthreads();
+    Scan(scan_tmp).ExclusiveSum((uint32_t)__popc(lmask), my_prim, all_prims);
+    __syncthreads();
+    Scan(scan_tmp).ExclusiveSum((uint32_t)__popc(imask), my_next, all_next);
+    if (threadIdx.x == 0) {
+        list_base[0] = all_slots ? atomicAdd(&cnt->slots, all_slots) : 0u;
+        list_base[1] = all_prims ? atomicAdd(&cnt->prim_records, all_prims) : 0u;
+        list_base[2] = all_next ? atomicAdd(&cnt->n_next, all_next) : 0u;
+    }
+    __syncthreads();
+    if (!valid) return;
     uint32_t cbase = 0;
     if (imask) {
-        // the node children's slots: from the lowest to the highest occupied child slot
-        const uint32_t low = (uint32_t)__ffs((int)imask) - 1u, span = 32u - (uint32_t)__clz((int)imask) - low;
-        const uint32_t first = atomicAdd(&cnt->slots, span);
+        const uint32_t first = list_base[0] + my_slot;
         if (first + span > slot_capacity) { cnt->overflow = 1u; return; }
         cbase = first - low;                   // (first >= 8 > low)
     }
-    const uint32_t pbase = atomicAdd(&cnt->prim_records, (uint32_t)__popc(lmask));
+    const uint32_t pbase = list_base[1] + my_prim;
     uint32_t rank = 0, boxless = 0;
     for (uint32_t k = 0; k < 8; k++) {
         if (!(lmask >> k & 1u)) continue;
@@ -237,7 +260,7 @@ k_split(const unsigned long long* __restrict__ keys, const float4* __restrict__ 
         rank++;
     }
     if (imask) {
-        uint32_t at = off_out + atomicAdd(&cnt->n_next, (uint32_t)__popc(imask));
+        uint32_t at = off_out + list_base[2] + my_next;
         for (uint32_t k = 0; k < 8; k++)
             if (imask >> k & 1u) runs[at++] = Run{cb[k], cb[k + 1], cbase + k, shift - 3};
     }
@@ -358,7 +381,6 @@ int build_wide_on_device(void* stream, const void* d_entries, uint32_t n_entries
         if (n_entries) HIP_OK(hipMemcpyAsync(&first_word, (const char*)d_entries + 12, 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
-    auto grid = [](size_t n) { return (uint32_t)std::min<size_t>(std::max<size_t>((n + WB - 1) / WB, 1), 65536); };
     // Box-less primitives exist unless one box spans every entry (a Bvh or a mesh at the root): only
     // then is the prefix maximum over the boxes' skip links needed.
     uint32_t* cover = nullptr;
