@@ -802,10 +802,12 @@ static int upload_tables(rt_scene* s, const FlatScene& f) {
     s->dev.kinds_present = f.kinds_present;
     s->dev.has_spheres = f.has_spheres ? 1u : 0u;
     // (kinds_present: bit k for material kind k; bits 0-2 are the kinds that scatter)
-    // RT_FUSE (experiments): 0 never, 1 Lambert-only scenes, 2 every scene
-    const int fuse_knob = std::getenv("RT_FUSE") ? std::atoi(std::getenv("RT_FUSE")) : 1;
+    // RT_FUSE (experiments): 0 never, 1 Lambert-only scenes, 2 every kind of every scene, 3 the Lambertian hits
+    // of every scene (dev.fuse: 1 Lambert-only scene, 2 every kind, 3 Lambertian hits of a scene with several kinds)
+    const int fuse_knob = std::getenv("RT_FUSE") ? std::atoi(std::getenv("RT_FUSE")) : 3;
     const bool lambert_only = (f.kinds_present & 7u) == (1u << RT_MAT_LAMBERT);
-    s->dev.fuse = s->dev.n_xforms != 0 || fuse_knob <= 0 ? 0u : lambert_only ? 1u : fuse_knob >= 2 ? 2u : 0u;
+    const bool has_lambert = (f.kinds_present & (1u << RT_MAT_LAMBERT)) != 0;
+    s->dev.fuse = s->dev.n_xforms != 0 || fuse_knob <= 0 ? 0u : lambert_only ? 1u : fuse_knob == 2 ? 2u : (fuse_knob >= 3 && has_lambert) ? 3u : 0u;
     return apply_traversal(s, s->traversal);
 }
 

@@ -1181,8 +1181,9 @@ __device__ __forceinline__ bool shade_one(const DevScene& sc, const float4& a, c
 
 // what happens to a traced ray: terminate it (sky, emitter, depth cap -> its radiance goes to
 // Lbuf) or record the hit and report the material kind it must be queued under (7 = none)
-// RECORD = false: the caller shades the ray itself right away and needs no hit record.
-template <bool RECORD = true>
+// RECORD = 0: the caller shades the ray itself right away and needs no hit record; 2: it does so for
+// Lambertian hits only.
+template <int RECORD = 1>
 __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
                                                const float4* __restrict__ C, uint2* __restrict__ hits,
                                                float4* __restrict__ Lbuf, uint32_t i, uint32_t slot, float dx,
@@ -1211,7 +1212,7 @@ __device__ __forceinline__ uint32_t finish_ray(const float4* __restrict__ mats, 
         Lbuf[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         return 7u;
     }
-    if (RECORD) hits[i] = make_uint2(f2u(t), prim);
+    if (RECORD == 1 || (RECORD == 2 && k != RT_MAT_LAMBERT)) hits[i] = make_uint2(f2u(t), prim);
     return k;
 }
 
@@ -1381,8 +1382,11 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
 // FUSE = RT_MAT_LAMBERT: scenes whose only scattering kind is Lambertian (the next depth then sees
 // the segment the queue would have given it, bit for bit); FUSE_ANY: every kind, one after the
 // other under the lanes' masks (the next depth's rays then stand in ray order instead of sorted by
-// material, which changes no path: a path's random numbers are keyed by pixel, sample and depth).
-constexpr int FUSE_ANY = 7;
+// material, which changes no path: a path's random numbers are keyed by pixel, sample and depth);
+// FUSE_LAMBERT_MIXED: scenes with several kinds -- Lambertian hits are shaded here, metal and
+// dielectric hits are recorded and queued for the shade stage, which appends behind them.
+constexpr int FUSE_ANY = 7, FUSE_LAMBERT_MIXED = 4;
+constexpr int fuse_record(int FUSE) { return FUSE < 0 ? 1 : FUSE == FUSE_LAMBERT_MIXED ? 2 : 0; }
 struct FuseOut {
     float4 *nA, *nB, *nC;      // the next depth's ray records
     uint32_t ctr;              // RNG counter base of this depth
@@ -1401,7 +1405,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
     auto shade_now = [&](uint32_t kind, uint32_t i, const float4& a, const float4& b, float t, uint32_t prim) {
         bool alive = false;
         float4 na = make_float4(0, 0, 0, 0), nb = na, nc = na;
-        const bool scatters = FUSE == FUSE_ANY ? kind < 3u : kind == (uint32_t)FUSE;
+        const bool scatters = FUSE == FUSE_ANY ? kind < 3u : kind == (uint32_t)(FUSE == FUSE_LAMBERT_MIXED ? RT_MAT_LAMBERT : FUSE);
         if (scatters) {
             const float4 c = C[i];
             if (FUSE == FUSE_ANY) {
@@ -1415,6 +1419,12 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
         const uint32_t pos = base + wave_append(alive, fuse->out);
         if (alive) { fuse->nA[pos] = na; fuse->nB[pos] = nb; fuse->nC[pos] = nc; }
         else if (scatters) Lbuf[f2u(a.w)] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // scatter() == false
+        if (FUSE == FUSE_LAMBERT_MIXED) {      // the other kinds wait in their queues for the shade stage
+            uint32_t qpos = wave_append(kind == 1u, n1);
+            if (kind == 1u) q1[base + qpos] = i;
+            qpos = wave_append(kind == 2u, n2);
+            if (kind == 2u) q2[base + qpos] = i;
+        }
     };
     const float4* ent = (const float4*)sc.entries;
     const float4* mats = (const float4*)sc.materials;
@@ -1443,9 +1453,9 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                       f32x2{a0.z, a1.z}, f32x2{b0.x, b1.x}, f32x2{b0.y, b1.y}, f32x2{b0.z, b1.z},
                                       t_min, t_max, h, cnt);
             uint32_t ka = 7u, kb = 7u;
-            if (va) ka = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0],
+            if (va) ka = finish_ray<fuse_record(FUSE)>(mats, sc.prim_meta, C, hits, Lbuf, ia, f2u(a0.w), b0.x, b0.y, b0.z, h.t[0],
                                                 h.prim[0], last_depth, sky_intensity);
-            if (vb) kb = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1],
+            if (vb) kb = finish_ray<fuse_record(FUSE)>(mats, sc.prim_meta, C, hits, Lbuf, ib, f2u(a1.w), b1.x, b1.y, b1.z, h.t[1],
                                                 h.prim[1], last_depth, sky_intensity);
             if (FUSE >= 0) {
                 shade_now(ka, ia, a0, b0, h.t[0], h.prim[0]);
@@ -1517,7 +1527,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
             else
                 closest_hit<COUNT, false, TIE>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
-                kind = finish_ray<(FUSE < 0)>(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
+                kind = finish_ray<fuse_record(FUSE)>(mats, sc.prim_meta, C, hits, Lbuf, i, f2u(a.w), b.x, b.y, b.z, t, prim, last_depth,
                                               sky_intensity);
             if (FUSE >= 0) shade_now(kind, i, a, b, t, prim);
             else enqueue(kind, i);
@@ -1717,6 +1727,14 @@ k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_
             trace_segment<false, SWEEP, TIE, FUSE>(sc, A, B, C, pb.hits, pb.q0, pb.q1, pb.q2, pb.Lbuf, base, n, lane, last ? 1u : 0u,
                                                    t_min, sky_intensity, n0, n1, n2, cnt, &fuse);
             n = fuse.out;
+            if (FUSE == FUSE_LAMBERT_MIXED && !last && (n1 | n2) != 0u) {
+                stage_fence();
+                const uint32_t ctr = d * 16u;
+                if (sc.kinds_present & 2u)
+                    shade_queue<RT_MAT_METAL>(sc, A, B, C, pb.hits, pb.q1, nA, nB, nC, pb.Lbuf, base, n1, ctr, lane, n);
+                if (sc.kinds_present & 4u)
+                    shade_queue<RT_MAT_DIELECTRIC>(sc, A, B, C, pb.hits, pb.q2, nA, nB, nC, pb.Lbuf, base, n2, ctr, lane, n);
+            }
             continue;
         }
 #ifdef RT_UTIL
@@ -1838,12 +1856,14 @@ int launch_path_walk(const LaunchCfg&, const DevScene&, const rt_camera&, const 
     hipLaunchKernelGGL((k_path<SWP, TIE, FUSE>), dim3((g.n_seg + RT_WPB - 1) / RT_WPB), dim3(RT_WAVE), lds, st, sc, g, cam, \
                        (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, sky_intensity RT_STAMP_ARG)
 #define RT_PATH_FUSED(SWP) do { if (sc.fuse == 2u) { if (sc.tie) RT_PATH_F(SWP, true, FUSE_ANY); else RT_PATH_F(SWP, false, FUSE_ANY); } \
+                                else if (sc.fuse == 3u) { if (sc.tie) RT_PATH_F(SWP, true, FUSE_LAMBERT_MIXED); else RT_PATH_F(SWP, false, FUSE_LAMBERT_MIXED); } \
                                 else if (sc.tie) RT_PATH_F(SWP, true, RT_MAT_LAMBERT); else RT_PATH_F(SWP, false, RT_MAT_LAMBERT); } while (0)
 #define RT_PATH_LDS_F(SWP, TIE, FUSE)                                                                   \
     hipLaunchKernelGGL((k_path<SWP, TIE, FUSE>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
                        bytes, st, sc, g, cam, (uint32_t)seed, (uint32_t)(seed >> 32), pb, max_bounces, t_min, \
                        sky_intensity RT_STAMP_ARG)
 #define RT_PATH_LDS_FUSED(SWP) do { if (sc.fuse == 2u) { if (sc.tie) RT_PATH_LDS_F(SWP, true, FUSE_ANY); else RT_PATH_LDS_F(SWP, false, FUSE_ANY); } \
+                                    else if (sc.fuse == 3u) { if (sc.tie) RT_PATH_LDS_F(SWP, true, FUSE_LAMBERT_MIXED); else RT_PATH_LDS_F(SWP, false, FUSE_LAMBERT_MIXED); } \
                                     else if (sc.tie) RT_PATH_LDS_F(SWP, true, RT_MAT_LAMBERT); else RT_PATH_LDS_F(SWP, false, RT_MAT_LAMBERT); } while (0)
 #define RT_PATH_LDS_T(SWP, TIE)                                                                         \
     hipLaunchKernelGGL((k_path<SWP, TIE>), dim3((g.n_seg + RT_LDS_BLOCK / 64 - 1) / (RT_LDS_BLOCK / 64)), dim3(RT_LDS_BLOCK), \
