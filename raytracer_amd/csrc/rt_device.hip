@@ -872,7 +872,8 @@ extern __shared__ uint32_t lds_stack[];
 //        3 = ordered per-lane walk, 4 = per-lane walk over a copy of the units in LDS (k_path only),
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
 //        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
-//        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only),
+//        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only;
+//        16 = 12 built for six waves per SIMD),
 //        13 / 14 / 15 = 9 out of LDS / with idle lanes refilled / both (k_path only)
 template <bool COUNT, int SWEEP, bool TIE>
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -1478,7 +1479,7 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                                          SplitCfg{(lds_units_ptr)lds_stack, sc.split_top, sc.deep_wait}, nullptr, mats, sc.prim_meta,
                                          A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0,
                                          n1, n2, cnt);
-    } else if (SWEEP == 12) {
+    } else if (SWEEP == 12 || SWEEP == 16) {
         wide_segment<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
                             lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
                             q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
@@ -1685,11 +1686,18 @@ __device__ __forceinline__ void stage_fence() {
 #ifndef RT_LDS_BLOCK
 #define RT_LDS_BLOCK 512
 #endif
+// The refilled wide walk over a tree that is read from HBM (a node per 128-byte line) runs with six
+// waves per SIMD instead of eight: with 80 registers its walk keeps everything in registers (four
+// values go to scratch memory at 64), and the waits it has to cover are for lines from HBM either way --
+// 10 M triangles +7 %; trees that sit in L2 lose 2-3 % by it and keep eight.
+#ifndef RT_WIDE_HBM_WAVES
+#define RT_WIDE_HBM_WAVES 6
+#endif
 // (the forms that keep a copy of the units, or of their top, in LDS: workgroups of eight waves)
 constexpr bool lds_form(int sweep) { return sweep == 4 || sweep == 6 || sweep == 10 || sweep == 13 || sweep == 15; }
 template <int SWEEP, bool TIE, int FUSE = -1>
 __global__ void __launch_bounds__(lds_form(SWEEP) ? RT_LDS_BLOCK : RT_WAVE)
-    __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(8, 8)))
+    __attribute__((amdgpu_num_sgpr(RT_TRACE_SGPRS), amdgpu_waves_per_eu(SWEEP == 16 ? RT_WIDE_HBM_WAVES : 8, 8)))
 k_path(DevScene sc, BatchGeom g, rt_camera cam, uint32_t seed_lo, uint32_t seed_hi, PathBuffers pb,
        uint32_t max_bounces, float t_min, float sky_intensity RT_STAMP_PARAM) {
     const uint32_t wpb = lds_form(SWEEP) ? RT_LDS_BLOCK / 64 : RT_WPB;
@@ -1928,7 +1936,12 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.wide) { if (sc.refill) RT_PATH_T(12, true); else RT_PATH_T(11, true); return check_launch(); }
+    if (sc.wide) {
+        if (!sc.refill) RT_PATH_T(11, true);
+        else if (sc.wide_stride == WIDE_LINE_WORDS / 4u) RT_PATH_T(16, true);   // (the stride counts uint4)
+        else RT_PATH_T(12, true);
+        return check_launch();
+    }
     if (sc.n_xforms) {                         // the per-lane walks that follow the transform markers
         if (sc.lds_walk) {
             const size_t bytes = (size_t)(sc.n_walk + UNITS_END) * 16u;
