@@ -1686,10 +1686,9 @@ __device__ __forceinline__ void stage_fence() {
 #ifndef RT_LDS_BLOCK
 #define RT_LDS_BLOCK 512
 #endif
-// The refilled wide walk over a tree that is read from HBM (a node per 128-byte line) runs with six
-// waves per SIMD instead of eight: with 80 registers its walk keeps everything in registers (four
-// values go to scratch memory at 64), and the waits it has to cover are for lines from HBM either way --
-// 10 M triangles +7 %; trees that sit in L2 lose 2-3 % by it and keep eight.
+// The refilled wide walk over a tree that is read from HBM (a node per 128-byte line) is built for six
+// waves per SIMD (80 registers) instead of eight (64): measured on 10 M triangles +8 % (seven waves
+// +6 %, five +3 %), while trees that sit in L2 lose 2-3 % by it and keep eight.
 #ifndef RT_WIDE_HBM_WAVES
 #define RT_WIDE_HBM_WAVES 6
 #endif
