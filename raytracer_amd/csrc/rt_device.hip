@@ -119,6 +119,20 @@ __device__ __forceinline__ uint32_t box_step(const float4& a, const float4& b, c
     return tmx <= tmn ? (f2u(a.w) & SKIP_MASK) : f2u(b.w);            // missed: the skip link; hit: the first child
 }
 
+// 1 / x.  v_rcp_f32 followed by two Newton steps with exact (fused) residuals is bit-identical to the
+// correctly rounded quotient for every f32 x with 2^-23 <= |x| <= 8.5e37 -- checked exhaustively over
+// all 2.5e9 such inputs on gfx950 by tools/rcp_check.hip -- and costs 5 instructions instead of 11.
+// The caller takes the full division when any lane is outside that range.
+constexpr float RCP_SHORT_MAX = 8.5e37f;
+__device__ __forceinline__ float rcp_short(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return r;
+}
+
 // shape.rs:411-450 on the triangle (a.xyz = v0, b.xyz = v0v1, c.xyz = v0v2, b.w = prim id)
 template <bool TIE = false>
 __device__ __forceinline__ void tri_step(const float4& a, const float4& b, const float4& c, LaneRay& r, float t_min) {
@@ -128,7 +142,11 @@ __device__ __forceinline__ void tri_step(const float4& a, const float4& b, const
     const float pz = r.dx * c.y - r.dy * c.x;
     const float det = dot3(b.x, b.y, b.z, px, py, pz);
     if (!(fabsf(det) < EPS)) {
-        const float inv_det = 1.0f / det;
+        // (lanes with |det| < eps have left, so only huge / non-finite determinants need the full
+        // division of shape.rs:434: inv_det = 1.0 / det)
+        float inv_det;
+        if (__ballot(!(fabsf(det) <= RCP_SHORT_MAX)) != 0ull) inv_det = 1.0f / det;
+        else inv_det = rcp_short(det);
         const float tx = r.ox - a.x, ty = r.oy - a.y, tz = r.oz - a.z;
         const float u = dot3(tx, ty, tz, px, py, pz) * inv_det;
         if (!(u < 0.0f || u > 1.0f)) {
@@ -665,12 +683,7 @@ __device__ __forceinline__ f32x2 dot3s(float ax, float ay, float az, f32x2 bx, f
 
 struct Hit2 { float t[2]; uint32_t prim[2]; };
 
-// 1 / x for both components.  v_rcp_f32 followed by two Newton steps with exact (fused)
-// residuals is bit-identical to the correctly rounded quotient for every f32 x with
-// 2^-23 <= |x| <= 8.5e37 -- checked exhaustively over all 2.5e9 such inputs on gfx950 by
-// tools/rcp_check.hip -- and costs 6 instructions for two rays instead of 22.  The caller takes
-// the full division when any lane is outside that range.
-constexpr float RCP_SHORT_MAX = 8.5e37f;
+// rcp_short for both components: 6 instructions for two rays instead of 22
 __device__ __forceinline__ f32x2 rcp_short2(f32x2 x) {
     f32x2 r = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
     const f32x2 one = {1.0f, 1.0f};
