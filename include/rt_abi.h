@@ -198,9 +198,12 @@ int rt_scene_set_root(rt_scene* scene, int root_kind);
  * ray severalfold on meshes that mix large and small triangles.  The box and primitive tests are
  * the reference's and exact ties in t are resolved by primitive key (see rt_scene_get_prim_order),
  * so the closest hit is the reference's primitive at the reference's t on every ray the tests and
- * fuzz campaigns of this library have traced; what is not excluded by construction is a box that
- * rounding closes in front of a primitive whose own test accepts the ray, which another tree's
- * boxes need not repeat.  AUTO (the default) builds both: the explicit traversal modes run on the
+ * fuzz campaigns of this library have traced with |d|^2 in [1e-30, 1e18); what is not excluded by
+ * construction is a box that rounding closes in front of a primitive whose own test accepts the
+ * ray, which another tree's boxes need not repeat, and outside that range of |d|^2 the reference's
+ * sphere test overflows or works on denormals and reports spheres whose boxes the ray misses, so
+ * its result there depends on which of its own boxes the ray passes (the surface-area trees group
+ * the objects of a Bvh their own way).  AUTO (the default) builds both: the explicit traversal modes run on the
  * reference's trees, and RT_TRAVERSAL_AUTO may move the scene to the surface-area trees on its
  * first render (see rt_scene_set_traversal).  A scene without a GPU context builds the
  * reference's trees only under AUTO. */
@@ -257,9 +260,11 @@ int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CA
  * of the node (80 bytes per node, always enclosing the true boxes), with every primitive a leaf of
  * its own.  A lane fetches a node, tests its eight boxes at once, and visits the children that were
  * hit nearest first, the rest waiting on a per-lane stack of one word per level.  The primitive
- * tests are the reference's, so t is theirs, and ties go by primitive key.  Fails with
- * RT_ERR_UNSUPPORTED for scenes with transformed meshes, trees deeper than 60 wide levels or of
- * 2^24 node slots and more.
+ * tests are the reference's, so t is theirs, and ties go by primitive key.  A transformed mesh
+ * (Mesh::new with a transform, shape.rs:236-257) is a node of its own, collapsed in the mesh's
+ * space: a lane that reaches it takes its ray there (Ray::transform, camera.rs:137-142, as
+ * Mesh::hit does, shape.rs:454) and restores it when the mesh's subtree is exhausted.  Fails with
+ * RT_ERR_UNSUPPORTED for trees deeper than 60 wide levels or of 2^24 node slots and more.
  * The explicit modes run on the reference's trees (on the surface-area trees for a scene built with
  * RT_BUILD_SAH).  May be called before or after rt_scene_commit(). */
 enum { RT_TRAVERSAL_AUTO = 0, RT_TRAVERSAL_PER_LANE = 1, RT_TRAVERSAL_SWEEP = 2, RT_TRAVERSAL_ORDERED = 3,
@@ -275,7 +280,8 @@ int rt_scene_set_traversal(rt_scene* scene, int mode);
  * collapsed ones where primitives are small and evenly spread, worse where sizes are mixed.  The
  * node children of a node take the slots from its lowest to its highest occupied child slot, not
  * first-fit compacted as on the host, so the limit of 2^24 node slots is reached earlier (the
- * 10 M-triangle soup: 6.9 M slots here, 3.7 M collapsed): roughly 20 M evenly spread triangles. */
+ * 10 M-triangle soup: 6.1 M slots here, 3.7 M collapsed): roughly 27 M evenly spread triangles.
+ * DEVICE does not take scenes with transformed meshes (RT_ERR_UNSUPPORTED when the tree is made). */
 enum { RT_WIDE_BUILD_COLLAPSE = 0, RT_WIDE_BUILD_DEVICE = 1 };
 int rt_scene_set_wide_build(rt_scene* scene, int where);
 /* builds the trees of the scene's build mode (the reference topology: shape.rs:94-138, 264-290),
@@ -322,7 +328,9 @@ int rt_scene_get_walk_units(const rt_scene* scene, float* out, size_t n_floats);
  * along x, y, z (step = 2^(e - 127)) and, in bits 24-31, the mask of child slots that hold nodes;
  * 4 the node slot of child slot 0 (child slot s lives at node slot [4] + s); 5 the index of the
  * node's first primitive record; 6 the mask of child slots that hold primitives (their records
- * follow each other in slot order); 7 the mask of child slots whose objects the reference tests
+ * follow each other in slot order); 7 in its upper 24 bits the number (from 1) of the transform when the
+ * node is the root of a transformed mesh's tree (whose nodes are in the mesh's own space), in its low
+ * byte the mask of child slots whose objects the reference tests
  * without a box test before them (the objects of a HittableList at the root: entered whatever their
  * boxes say by rays whose |d|^2 is outside [1e-30, 1e18), where the reference's sphere test overflows
  * or works on denormals and accepts points that have nothing to do with the sphere's box); 8-19 the children's planes, one byte per slot, two words per

@@ -527,7 +527,9 @@ static void bind_tree(rt_scene* s, int which) {
     s->dev.lds_walk = t.lds_walk ? 1u : 0u;
     s->dev.wide_nodes = t.d_wide_nodes.p;
     s->dev.wide_prims = t.d_wide_prims.p;
-    s->dev.wide_stack = std::max(1u, t.wide.depth);
+    // (a scene with transformed meshes: one slot more for the marker under a mesh's subtree, and six behind the
+    // stack for the caller's ray while the lane is inside a mesh)
+    s->dev.wide_stack = std::max(1u, t.wide.depth) + (s->dev.n_xforms ? 1u + WIDE_XF_RAY_SLOTS : 0u);
     s->dev.wide_stride = t.wide.node_words / 4u;
 }
 
@@ -557,6 +559,8 @@ static int ensure_wide_tree(rt_scene* s) {
     SceneTree& t = s->tree();
     const int which = s->cur;
     if (!t.d_wide_nodes.p && s->wide_build == RT_WIDE_BUILD_DEVICE) {
+        if (s->dev.n_xforms != 0)
+            return fail(RT_ERR_UNSUPPORTED, "wide traversal: the device-side build does not take transformed meshes (RT_WIDE_BUILD_COLLAPSE does)");
         int rc = set_device(s->ctx);
         if (rc) return rc;
         WideDeviceTree w;
@@ -578,9 +582,11 @@ static int ensure_wide_tree(rt_scene* s) {
         if (rc) return rc;
         std::vector<float> entries((size_t)t.n_entries * ENTRY_FLOATS);
         HIP_TRY(hipMemcpy(entries.data(), t.d_entries.p, entries.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<float> xforms((size_t)s->dev.n_xforms * 32);
+        if (!xforms.empty()) HIP_TRY(hipMemcpy(xforms.data(), s->d_xforms.p, xforms.size() * 4, hipMemcpyDeviceToHost));
         WideScene w;
         const auto t_begin = std::chrono::steady_clock::now();
-        const std::string err = build_wide_scene(entries.data(), t.n_entries, w);
+        const std::string err = build_wide_scene(entries.data(), t.n_entries, w, xforms.empty() ? nullptr : xforms.data(), s->dev.n_xforms);
         if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
         if (std::getenv("RT_BUILD_TIMING"))
             std::fprintf(stderr, "[rt build] wide tree                    %.3f s (%zu node slots, %zu primitives, %u levels)\n",
@@ -614,8 +620,8 @@ static int ensure_wide_tree(rt_scene* s) {
 static int apply_traversal(rt_scene* s, int mode) {
     bind_tree(s, s->base_tree());
     const SceneTree& t = s->tree();
-    if (s->dev.n_xforms != 0 && mode != RT_TRAVERSAL_AUTO && mode != RT_TRAVERSAL_PER_LANE)
-        return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
+    if (s->dev.n_xforms != 0 && mode != RT_TRAVERSAL_AUTO && mode != RT_TRAVERSAL_PER_LANE && mode != RT_TRAVERSAL_WIDE)
+        return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk or the wide walk only");
     if (mode == RT_TRAVERSAL_ORDERED && t.multi_child)
         return fail(RT_ERR_UNSUPPORTED, "ordered traversal takes boxes of at most two children (no leaves of several triangles, "
                                         "no list inside a Bvh); the octant traversal visits the same entries without that limit");
@@ -942,9 +948,9 @@ int rt_scene_get_units(const rt_scene* s, float* out, size_t n_floats) {
 static int host_wide(const rt_scene* cs) {
     rt_scene* s = const_cast<rt_scene*>(cs);
     if (!s->committed || s->ctx) return fail(RT_ERR_STATE, "the wide tree can be inspected on a committed host-only scene");
-    if (!s->flat.xforms.empty()) return fail(RT_ERR_UNSUPPORTED, "a scene with transformed meshes is traced by the per-lane walk only");
     if (s->tree().wide.nodes.empty()) {
-        const std::string err = build_wide_scene(s->flat.entries.data(), s->flat.n_entries(), s->tree().wide);
+        const std::string err = build_wide_scene(s->flat.entries.data(), s->flat.n_entries(), s->tree().wide,
+                                                 s->flat.xforms.empty() ? nullptr : s->flat.xforms.data(), s->flat.xforms.size() / 32);
         if (!err.empty()) return fail(RT_ERR_UNSUPPORTED, "wide traversal: " + err);
     }
     return RT_OK;
@@ -1185,7 +1191,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             // applies it is taken without a timing: on frames of real size it beat both binary walks on
             // every such scene measured (cornell_box.obj 1.15-1.4x, 10 M triangles 3.6x), and a timing of
             // three whole batches costs a one-frame job several times its frame.
-            if (fast && !s->trees[TREE_FAST].lds_walk && s->dev.n_xforms == 0 && !std::getenv("RT_AUTO_NO_WIDE")) {
+            if (fast && !s->trees[TREE_FAST].lds_walk && !std::getenv("RT_AUTO_NO_WIDE")) {
                 const int was = s->cur;
                 bind_tree(s, TREE_FAST);
                 const int wrc = ensure_wide_tree(s);

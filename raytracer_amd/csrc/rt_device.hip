@@ -547,11 +547,15 @@ struct WideLane {
     bool wild;                 // |d|^2 is outside [1e-30, 1e18) or a NaN: the reference's sphere test overflows (and
                                // accepts) or works on denormals (and accepts points far outside the sphere)
 };
-__device__ __forceinline__ void wide_lane_init(WideLane& w, bool valid, float dx, float dy, float dz) {
+// what the walk derives from a ray's direction (again when the ray enters or leaves a transformed mesh)
+__device__ __forceinline__ void wide_lane_dir(WideLane& w, float dx, float dy, float dz) {
     w.rb = (dx >= 0.0f ? 1u : 0u) | (dy >= 0.0f ? 2u : 0u) | (dz >= 0.0f ? 4u : 0u);
-    w.G = valid ? 1u << w.rb : 0u;             // the root is "child rb ^ rb = 0 of the group at node slot 0"
     const float dd = dot3(dx, dy, dz, dx, dy, dz);
     w.wild = !(dd < 1.0e18f && dd > 1.0e-30f);
+}
+__device__ __forceinline__ void wide_lane_init(WideLane& w, bool valid, float dx, float dy, float dz) {
+    wide_lane_dir(w, dx, dy, dz);
+    w.G = valid ? 1u << w.rb : 0u;             // the root is "child rb ^ rb = 0 of the group at node slot 0"
     w.sp = 0;
     w.pend = 0; w.pbase = 0; w.lmask = 0;
 }
@@ -561,24 +565,61 @@ __device__ __forceinline__ bool wide_live(const WideLane& w) { return w.pend != 
 // with primitives of their last node in hand test one of them, once prim_wait lanes wait (or no lane
 // needs a node).  `stack` is this wave's LDS region, slot s of a lane at stack[s * 64 + lane].
 // Returns false when no lane has anything left.
-template <bool COUNT>
+// XF (scenes with transformed meshes): the root node of a mesh's tree names the mesh's transform.  A lane
+// that fetches such a root puts its ray away (six LDS slots behind its stack, from `xf_slot`), pushes a
+// marker under the subtree and goes on with the ray in the mesh's space (Mesh::hit, shape.rs:454; t is
+// the same parameter there, so best_t carries over); when the marker comes off the stack the subtree
+// is exhausted and the caller's ray is back.  Meshes are leaves of the scene, so one saved ray does.
+constexpr uint32_t WIDE_XF_MARK = 0xFFFFFF00u;     // (a group without children at a node slot no tree has)
+template <bool COUNT, bool XF = false>
 __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                           uint32_t prim_wait, uint32_t* stack, uint32_t lane, LaneRay& r,
-                                          WideLane& w, float t_min, Counts& cnt) {
+                                          WideLane& w, float t_min, Counts& cnt, const float4* __restrict__ xforms = nullptr,
+                                          uint32_t xf_slot = 0) {
     const bool at_prim = w.pend != 0u;
     const bool at_node = !at_prim && ((w.G & 0xFFu) != 0u || w.sp != 0u);
     const unsigned long long mb = __ballot(at_node), mp = __ballot(at_prim);
     if ((mb | mp) == 0ull) return false;
     RT_UTIL_TRIP(cnt);
-    if (at_node) {
+    bool take_node = at_node;
+    uint32_t G = w.G;
+    if (at_node && (G & 0xFFu) == 0u) {
+        w.sp--;
+        G = stack[w.sp * 64u + lane];
+        if (XF && G == WIDE_XF_MARK) {          // the mesh's tree is exhausted: the caller's ray again
+            r.ox = u2f(stack[(xf_slot + 0u) * 64u + lane]); r.oy = u2f(stack[(xf_slot + 1u) * 64u + lane]);
+            r.oz = u2f(stack[(xf_slot + 2u) * 64u + lane]); r.dx = u2f(stack[(xf_slot + 3u) * 64u + lane]);
+            r.dy = u2f(stack[(xf_slot + 4u) * 64u + lane]); r.dz = u2f(stack[(xf_slot + 5u) * 64u + lane]);
+            r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;
+            wide_lane_dir(w, r.dx, r.dy, r.dz);
+            G = 0u;
+            if (w.sp != 0u) { w.sp--; G = stack[w.sp * 64u + lane]; }
+            take_node = (G & 0xFFu) != 0u;
+            w.G = G;
+        }
+    }
+    if (take_node) {
         if (COUNT) cnt.box++;
-        uint32_t G = w.G;
-        if ((G & 0xFFu) == 0u) { w.sp--; G = stack[w.sp * 64u + lane]; }
-        const uint32_t rb = w.rb;
+        uint32_t rb = w.rb;
         const uint32_t p = 31u - (uint32_t)__clz((int)(G & 0xFFu));
         G ^= 1u << p;
         const uint4* np = nodes + (size_t)((G >> 8) + (p ^ rb)) * stride;
         const uint4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4];
+        if (XF && (q1.w >> 8) != 0u) {           // the root of a transformed mesh's tree
+            stack[(xf_slot + 0u) * 64u + lane] = f2u(r.ox); stack[(xf_slot + 1u) * 64u + lane] = f2u(r.oy);
+            stack[(xf_slot + 2u) * 64u + lane] = f2u(r.oz); stack[(xf_slot + 3u) * 64u + lane] = f2u(r.dx);
+            stack[(xf_slot + 4u) * 64u + lane] = f2u(r.dy); stack[(xf_slot + 5u) * 64u + lane] = f2u(r.dz);
+            if ((G & 0xFFu) != 0u) { stack[w.sp * 64u + lane] = G; w.sp++; }
+            stack[w.sp * 64u + lane] = WIDE_XF_MARK; w.sp++;
+            G = 0u;
+            const float4* inv = xforms + 8u * ((q1.w >> 8) - 1u) + 4u;
+            const float wox = r.ox, woy = r.oy, woz = r.oz, wdx = r.dx, wdy = r.dy, wdz = r.dz;
+            xf_apply(inv, wox, woy, woz, 1.0f, r.ox, r.oy, r.oz);       // camera.rs:137-142
+            xf_apply(inv, wdx, wdy, wdz, 0.0f, r.dx, r.dy, r.dz);
+            r.ix = 1.0f / r.dx; r.iy = 1.0f / r.dy; r.iz = 1.0f / r.dz;  // math.rs:152
+            wide_lane_dir(w, r.dx, r.dy, r.dz);
+            rb = w.rb;
+        }
         const bool nx = r.ix < 0.0f, ny = r.iy < 0.0f, nz = r.iz < 0.0f;
         const float sx = u2f((q0.w & 0xFFu) << 23) * r.ix;
         const float sy = u2f((q0.w >> 8 & 0xFFu) << 23) * r.iy;
@@ -607,7 +648,7 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint3
         // (the root then lies anywhere) gets "hits" that have nothing to do with the sphere's box, and the
         // reference tests the objects of a list at the root without any box: such a ray enters the
         // children that stand for those objects whatever their boxes say.
-        hm |= w.wild ? q1.w : 0u;
+        hm |= w.wild ? (q1.w & 0xFFu) : 0u;
         const uint32_t imask = q0.w >> 24;
         w.lmask = q1.z;
         w.pbase = q1.y;
@@ -640,16 +681,17 @@ __device__ __forceinline__ bool wide_trip(const uint4* __restrict__ nodes, uint3
     return true;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool XF = false>
 __device__ __forceinline__ void closest_hit_wide(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                                  uint32_t prim_wait, uint32_t* stack, uint32_t lane, bool valid,
                                                  float ox, float oy, float oz, float dx, float dy, float dz,
-                                                 float t_min, float& best_t, uint32_t& best_prim, Counts& cnt) {
+                                                 float t_min, float& best_t, uint32_t& best_prim, Counts& cnt,
+                                                 const float4* __restrict__ xforms = nullptr, uint32_t xf_slot = 0) {
     LaneRay r;
     lane_ray_init<true>(r, ox, oy, oz, dx, dy, dz, best_t);
     WideLane w;
     wide_lane_init(w, valid, dx, dy, dz);
-    while (wide_trip<COUNT>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt)) {}
+    while (wide_trip<COUNT, XF>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt, xforms, xf_slot)) {}
     best_t = r.best_t;
     best_prim = key_result<true>(r.best_prim);
 }
@@ -886,7 +928,7 @@ extern __shared__ uint32_t lds_stack[];
 //        5 / 6 = 0 / 4 with idle lanes refilled (k_path only), 7 = per-lane walk of the ray's octant copy,
 //        8 = 7 with idle lanes refilled (k_path only), 9 = per-lane walk of a scene with transformed meshes,
 //        11 = stack walk of the wide tree (10 is the split walk, k_path only), 12 = 11 with idle lanes refilled (k_path only;
-//        16 = 12 built for six waves per SIMD),
+//        16 = 12 built for six waves per SIMD; 17 / 18 = 11 / 12 for scenes with transformed meshes),
 //        13 / 14 / 15 = 9 out of LDS / with idle lanes refilled / both (k_path only)
 template <bool COUNT, int SWEEP, bool TIE>
 __global__ void __launch_bounds__(RT_BLOCK)
@@ -934,6 +976,10 @@ k_trace_api(DevScene sc, const float* __restrict__ rays, size_t n, float t_min, 
             else if (SWEEP == 9)
                 closest_hit<COUNT, false, TIE, true>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, ox, oy, oz, dx, dy, dz, t_min, t, prim, cnt,
                                                      (const float4*)sc.xforms);
+            else if (SWEEP == 17)
+                closest_hit_wide<COUNT, true>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
+                                              lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid, ox, oy, oz, dx,
+                                              dy, dz, t_min, t, prim, cnt, (const float4*)sc.xforms, sc.wide_stack - WIDE_XF_RAY_SLOTS);
             else if (SWEEP == 11)
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, threadIdx.x & 63u, valid,
@@ -1332,7 +1378,7 @@ __device__ __forceinline__ void walk_segment(const float4* __restrict__ ent, uin
 // The wide walk over a whole segment with idle lanes refilled, as walk_segment does for the per-lane
 // walk: the wide walk is bound by instruction issue, and a wave that runs until its longest ray ends
 // issues most of its instructions for a few lanes.
-template <bool COUNT>
+template <bool COUNT, bool XF = false>
 __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, uint32_t stride, const float4* __restrict__ prims,
                                              uint32_t prim_wait, uint32_t refill_min, uint32_t* stack, uint32_t lane,
                                              const float4* __restrict__ mats, const uint32_t* __restrict__ prim_meta,
@@ -1341,7 +1387,8 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
                                              uint32_t* __restrict__ q0, uint32_t* __restrict__ q1,
                                              uint32_t* __restrict__ q2, float4* __restrict__ Lbuf, uint32_t base,
                                              uint32_t n, uint32_t last_depth, float t_min, float sky_intensity,
-                                             uint32_t& n0, uint32_t& n1, uint32_t& n2, Counts& cnt) {
+                                             uint32_t& n0, uint32_t& n1, uint32_t& n2, Counts& cnt,
+                                             const float4* __restrict__ xforms = nullptr, uint32_t xf_slot = 0) {
     LaneRay r;
     lane_ray_init<true>(r, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, __builtin_inff());
     WideLane w;
@@ -1383,7 +1430,7 @@ __device__ __forceinline__ void wide_segment(const uint4* __restrict__ nodes, ui
                 continue;
             }
         }
-        wide_trip<COUNT>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt);
+        wide_trip<COUNT, XF>(nodes, stride, prims, prim_wait, stack, lane, r, w, t_min, cnt, xforms, xf_slot);
     }
 }
 
@@ -1496,6 +1543,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
         wide_segment<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
                             lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
                             q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt);
+    } else if (SWEEP == 18) {                  // the refilled wide walk of a scene with transformed meshes
+        wide_segment<COUNT, true>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait, sc.refill,
+                                  lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, mats, sc.prim_meta, A, B, C, hits,
+                                  q0, q1, q2, Lbuf, base, n, last_depth, t_min, sky_intensity, n0, n1, n2, cnt,
+                                  (const float4*)sc.xforms, sc.wide_stack - WIDE_XF_RAY_SLOTS);
     } else if (SWEEP == 8) {
         walk_segment<COUNT, true, true>((const float4*)sc.units_oct, sc.n_units, sc.prim_wait, sc.refill, SplitCfg{nullptr, 0u, 0u},
                                   nullptr, mats, sc.prim_meta, A, B, C, hits, q0, q1, q2, Lbuf, base, n, last_depth, t_min,
@@ -1538,6 +1590,11 @@ __device__ __forceinline__ void trace_segment(const DevScene& sc, const float4* 
                 closest_hit_wide<COUNT>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
                                         lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
                                         b.x, b.y, b.z, t_min, t, prim, cnt);
+            else if (SWEEP == 17)              // the wide walk of a scene with transformed meshes
+                closest_hit_wide<COUNT, true>((const uint4*)sc.wide_nodes, sc.wide_stride, (const float4*)sc.wide_prims, sc.prim_wait,
+                                              lds_stack + (threadIdx.x >> 6) * sc.wide_stack * 64u, lane, valid, a.x, a.y, a.z,
+                                              b.x, b.y, b.z, t_min, t, prim, cnt, (const float4*)sc.xforms,
+                                              sc.wide_stack - WIDE_XF_RAY_SLOTS);
             else
                 closest_hit<COUNT, false, TIE>((const float4*)sc.walk, sc.n_walk, sc.prim_wait, valid, a.x, a.y, a.z, b.x, b.y, b.z, t_min, t, prim, cnt);
             if (valid)
@@ -1916,7 +1973,8 @@ int launch_trace_api_walk(const LaunchCfg& cfg, const DevScene& sc, const void* 
                           float t_max, void* d_hits, Totals* d_counts, bool count, uint32_t grid) {
     hipStream_t st = (hipStream_t)cfg.stream;
     const size_t lds = stack_bytes(sc, RT_BLOCK / 64);
-    if (sc.wide) { if (count) RT_TRACE_API_T(true, 11, true); else RT_TRACE_API_T(false, 11, true); }
+    if (sc.wide && sc.n_xforms) { if (count) RT_TRACE_API_T(true, 17, true); else RT_TRACE_API_T(false, 17, true); }
+    else if (sc.wide) { if (count) RT_TRACE_API_T(true, 11, true); else RT_TRACE_API_T(false, 11, true); }
     else if (sc.n_xforms) { if (count) RT_TRACE_API(true, 9); else RT_TRACE_API(false, 9); }
     else if (sc.octant) { if (count) RT_TRACE_API_T(true, 7, true); else RT_TRACE_API_T(false, 7, true); }
     else if (sc.ordered) { if (count) RT_TRACE_API_T(true, 3, true); else RT_TRACE_API_T(false, 3, true); }
@@ -1932,7 +1990,8 @@ int launch_trace_walk(const LaunchCfg& cfg, const DevScene& sc, const BatchGeom&
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = (!count && stamped_launches < STAMP_SLOTS) ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
-    if (sc.wide) { if (count) RT_TRACE_T(true, 11, true); else RT_TRACE_T(false, 11, true); }
+    if (sc.wide && sc.n_xforms) { if (count) RT_TRACE_T(true, 17, true); else RT_TRACE_T(false, 17, true); }
+    else if (sc.wide) { if (count) RT_TRACE_T(true, 11, true); else RT_TRACE_T(false, 11, true); }
     else if (sc.n_xforms) { if (count) RT_TRACE(true, 9); else RT_TRACE(false, 9); }
     else if (sc.octant) { if (count) RT_TRACE_T(true, 7, true); else RT_TRACE_T(false, 7, true); }
     else if (sc.ordered) { if (count) RT_TRACE_T(true, 3, true); else RT_TRACE_T(false, 3, true); }
@@ -1948,6 +2007,10 @@ int launch_path_walk(const LaunchCfg& cfg, const DevScene& sc, const rt_camera& 
 #ifdef RT_STAMPS
     const uint32_t stamp_slot = stamped_launches < STAMP_SLOTS ? stamped_launches++ : 0xFFFFFFFFu;
 #endif
+    if (sc.wide && sc.n_xforms) {
+        if (sc.refill) RT_PATH_T(18, true); else RT_PATH_T(17, true);
+        return check_launch();
+    }
     if (sc.wide) {
         if (!sc.refill) RT_PATH_T(11, true);
         else if (sc.wide_stride == WIDE_LINE_WORDS / 4u) RT_PATH_T(16, true);   // (the stride counts uint4)

@@ -170,6 +170,7 @@ void build_octant_units(const uint32_t* units, size_t n_units, std::vector<uint3
 //   5     index of the node's first primitive record (those of its primitive slots follow in slot order)
 //   6     mask of the slots that hold primitives
 //   7     mask of the slots whose children the reference reaches without a box test (objects of a list at the root)
+//         | (index of the transform + 1) << 8 when the node is the root of a transformed mesh's tree
 //   8-19  planes, one byte per slot: min x, min y, min z, max x, max y, max z (two words each);
 //         plane = origin + byte * step
 // One primitive record = 16 floats: the first three float4 of the primitive's entry.
@@ -182,6 +183,7 @@ constexpr uint32_t WIDE_LINE_WORDS = 32;
 constexpr size_t WIDE_PACKED_MAX_BYTES = (size_t)32 << 20;
 constexpr uint32_t WIDE_PRIM_FLOATS = 16;
 constexpr uint32_t WIDE_MAX_DEPTH = 60;        // stack slots per lane the walk may need (one per level)
+constexpr uint32_t WIDE_XF_RAY_SLOTS = 6;      // behind a lane's stack: the caller's ray while the lane walks a transformed mesh
 struct WideScene {
     std::vector<uint32_t> nodes;
     std::vector<float> prims;
@@ -190,9 +192,10 @@ struct WideScene {
     size_t n_nodes() const { return nodes.size() / node_words; }
     size_t n_prims() const { return prims.size() / WIDE_PRIM_FLOATS; }
 };
-// collapses the pre-order entry array (without transformed meshes) into a wide tree; returns an
-// empty string on success
-std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out);
+// collapses the pre-order entry array into a wide tree; returns an empty string on success.
+// `xforms`: FlatScene::xforms (32 floats per transformed mesh) when the array holds ENTER / LEAVE markers
+std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out, const float* xforms = nullptr,
+                             size_t n_xforms = 0);
 
 // The same tree built on the GPU from the device's entry array (rt_wide_device.hip): Morton-sorted
 // primitives, children = runs of equal Morton digit.  The arrays are device memory the caller owns

@@ -27,6 +27,13 @@
 // under boxes stay behind their own boxes for such rays too: there the reference's result depends
 // on which of its boxes rounding leaves open, which no other tree can repeat.)
 //
+// Transformed meshes (Mesh::hit transforms the ray before it descends, shape.rs:454): the tree of such
+// a mesh -- the entries between its ENTER and LEAVE markers -- is collapsed on its own, in the mesh's
+// space, and its root node carries the transform's number in the upper bits of word 7.  In the node
+// above it is an ordinary node child whose box is the mesh's local root box taken to the caller's
+// space (its eight corners, padded).  The walk transforms a lane's ray when it fetches such a root and
+// restores it when the subtree is exhausted; t is the same parameter in both spaces.
+//
 // Child slots and order: a child sits in the slot whose diagonal (bit k of the slot index: the
 // positive side along axis k) matches the offset of its centre from the node's centre best, so a
 // ray whose direction is positive along the axes in `r` meets the children roughly in descending
@@ -78,6 +85,7 @@ struct Item {
     std::shared_ptr<std::vector<Item>> group;
     WBox box;
     size_t span = 1;               // entries beneath (what decides whether a subtree gets a thread)
+    uint32_t xform = 0;            // a transformed mesh (entry = its ENTER marker): the transform's index + 1
     // a primitive the reference tests without any box test before it (an object of a HittableList at
     // the root, shape.rs:60-74, or the root itself), or a group made up here that holds one
     bool always = false;
@@ -86,11 +94,16 @@ struct Item {
 struct WideBuilder {
     const float* E;
     size_t n;
+    const float* X = nullptr;      // 32 floats per transform: its four columns, then its inverse's
 
     uint32_t word(size_t i, int w) const { uint32_t u; std::memcpy(&u, E + i * ENTRY_FLOATS + w, 4); return u; }
     uint32_t tag(size_t i) const { return word(i, 3) >> TAG_SHIFT; }
     size_t skip(size_t i) const { return word(i, 3) & SKIP_MASK; }
-    size_t next_sibling(size_t i) const { return tag(i) == TAG_BOX ? skip(i) : i + 1; }
+    bool is_enter(size_t i) const { return tag(i) == TAG_END && word(i, 0) == END_CODE_ENTER; }
+    size_t next_sibling(size_t i) const {
+        if (is_enter(i)) return next_sibling(i + 1) + 1;       // ENTER, the mesh's tree, LEAVE
+        return tag(i) == TAG_BOX ? skip(i) : i + 1;
+    }
 
     // A primitive's own box: the triangle the intersection routine sees (v0, v0 + e1, v0 + e2) or the
     // sphere, grown by the reference's 0.0001 (compute_aabb, shape.rs:225-231) plus four ulps of its
@@ -121,23 +134,45 @@ struct WideBuilder {
     Item entry_item(size_t i) const {
         Item it;
         it.entry = i;
+        if (is_enter(i)) {
+            // the mesh's local root box in the caller's space: its corners through the transform, padded by
+            // what the rounding of the transformed ray and of the corners may cost
+            const Item root = entry_item(i + 1);
+            it.xform = word(i, 1) + 1u;
+            it.span = root.span + 2;
+            it.box = wempty();
+            const float* m = X + (size_t)(it.xform - 1u) * 32;
+            for (int c = 0; c < 8; c++) {
+                const double x = (c & 1) ? root.box.hi[0] : root.box.lo[0], y = (c & 2) ? root.box.hi[1] : root.box.lo[1],
+                             z = (c & 4) ? root.box.hi[2] : root.box.lo[2];
+                for (int k = 0; k < 3; k++) {
+                    const double v = (double)m[k] * x + (double)m[4 + k] * y + (double)m[8 + k] * z + (double)m[12 + k];
+                    it.box.lo[k] = std::min(it.box.lo[k], (float)std::nextafter((float)v, -std::numeric_limits<float>::infinity()));
+                    it.box.hi[k] = std::max(it.box.hi[k], (float)std::nextafter((float)v, std::numeric_limits<float>::infinity()));
+                }
+            }
+            float big = 0.0f;
+            for (int k = 0; k < 3; k++) big = std::max(big, std::max(std::fabs(it.box.lo[k]), std::fabs(it.box.hi[k])));
+            const float pad = 0.0002f + big * 1.52587891e-5f;     // 2^-16
+            for (int k = 0; k < 3; k++) { it.box.lo[k] -= pad; it.box.hi[k] += pad; }
+            return it;
+        }
         if (tag(i) == TAG_BOX) { it.box = stored_box(i); it.span = skip(i) - i; }
         else { it.box = prim_box(i); it.span = 1; }
         return it;
     }
-    bool is_prim(const Item& it) const { return !it.group && tag(it.entry) != TAG_BOX; }
+    bool is_prim(const Item& it) const { return !it.group && !it.xform && tag(it.entry) != TAG_BOX; }
     size_t child_count(const Item& it) const {
         if (it.group) return it.group->size();
+        if (it.xform) return 1;
         size_t k = 0;
         for (size_t c = it.entry + 1, end = skip(it.entry); c < end; c = next_sibling(c)) k++;
         return k;
     }
     void children(const Item& it, std::vector<Item>& out) const {
         if (it.group) { out.insert(out.end(), it.group->begin(), it.group->end()); return; }
-        for (size_t c = it.entry + 1, end = skip(it.entry); c < end; c = next_sibling(c)) {
-            if (tag(c) == TAG_END) continue;           // (markers of transformed meshes never get here)
-            out.push_back(entry_item(c));
-        }
+        if (it.xform) { out.push_back(entry_item(it.entry + 1)); return; }     // the mesh's own root, in its own space
+        for (size_t c = it.entry + 1, end = skip(it.entry); c < end; c = next_sibling(c)) out.push_back(entry_item(c));
     }
 
     // more than eight candidates that cannot be merged by the trees themselves (a HittableList of many
@@ -205,7 +240,7 @@ struct WideBuilder {
             double best_area = -1.0;
             bool dropped = false;
             for (size_t i = 0; i < items.size(); i++) {
-                if (is_prim(items[i])) continue;
+                if (is_prim(items[i]) || items[i].xform) continue;     // (a transformed mesh stays a node of its own)
                 const size_t k = child_count(items[i]);
                 if (k == 0) { items.erase(items.begin() + (long)i); dropped = true; break; }
                 if (items.size() - 1 + k > 8) continue;
@@ -333,6 +368,14 @@ struct WideBuilder {
         // a child that turned out empty (a container of nothing) leaves its slot
         for (int s = 0; s < 8; s++)
             if ((imask >> s & 1) && !wvalid(cbox[s])) imask &= ~(1u << s);
+        // a transformed mesh: its root node names the transform, and its box up here is the one in this space
+        for (int s = 0; s < 8; s++) {
+            if (!(imask >> s & 1)) continue;
+            const Item& it = items[(size_t)child_in[s]];
+            if (!it.xform) continue;
+            A.nodes[(child_base + (size_t)s) * WIDE_NODE_WORDS + 7] |= it.xform << 8;
+            cbox[s] = it.box;
+        }
         WBox all = wempty();
         for (int s = 0; s < 8; s++)
             if ((imask | lmask) >> s & 1) wgrow(all, cbox[s]);
@@ -427,14 +470,14 @@ void compact_nodes(std::vector<uint32_t>& nodes) {
     nodes.swap(out);
 }
 
-std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out) {
+std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out, const float* xforms, size_t n_xforms) {
     out = WideScene();
-    WideBuilder b{entries, n_entries};
+    WideBuilder b{entries, n_entries, xforms};
     std::vector<Item> top;
     for (size_t i = 0; i < n_entries; i = b.next_sibling(i)) {
-        if (b.tag(i) == TAG_END) return "the wide tree does not take transformed meshes";
+        if (b.tag(i) == TAG_END && !(b.is_enter(i) && xforms && b.word(i, 1) < n_xforms)) return "internal error: wide tree: a stray marker";
         top.push_back(b.entry_item(i));
-        top.back().always = b.tag(i) != TAG_BOX;
+        top.back().always = b.tag(i) != TAG_BOX && !top.back().xform;
     }
     Arena A;
     A.nodes.assign(WIDE_NODE_WORDS, 0u);

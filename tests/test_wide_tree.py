@@ -226,14 +226,41 @@ def test_wide_tree_of_the_obj_scenes(rt, ob):
         assert wide_nodes * 2 < boxes
 
 
-def test_wide_tree_refuses_transformed_meshes(rt, ob):
+def test_wide_tree_holds_a_transformed_mesh_as_a_node_of_its_own(rt, ob):
+    """Mesh::hit transforms the ray before it descends (shape.rs:454): in the wide tree the mesh's tree is
+    collapsed in the mesh's own space, its root node names the transform (upper bits of word 7), and
+    the box it has in the node above encloses the mesh as the caller sees it."""
     mats, _, _ = random_scene(ob, 5)
     rng = np.random.default_rng(1)
     m = np.eye(4, dtype=np.float32)
-    m[3, 0] = 2.0
-    sc = rt.Scene(None, mats, [("mesh", random_mesh(ob, rng, 5), m.reshape(-1))], ob.ROOT_SINGLE)
-    with pytest.raises(rt.RtError):
-        sc.wide()
+    m[3, 0:3] = (2.0, -1.0, 0.5)                                       # (column-major: the translation)
+    m[0, 0], m[1, 1] = 1.5, 0.75
+    tris = random_mesh(ob, rng, 40)
+    sc = rt.Scene(None, mats, [("mesh", tris, m.reshape(-1)), ("mesh", random_mesh(ob, rng, 30))], ob.ROOT_BVH)
+    nodes, prims, depth = sc.wide()
+    assert len(prims) == 70
+    named = np.nonzero(nodes[:, 7] >> 8)[0]
+    assert len(named) == 1 and nodes[named[0], 7] >> 8 == 1            # one mesh's root, transform number 1
+    # find its slot in the node above and compare that box with the transformed vertices
+    world = tris["p"].reshape(-1, 3).astype(np.float64) * np.array([1.5, 0.75, 1.0]) + np.array([2.0, -1.0, 0.5])
+    found = False
+    for n in nodes:
+        imask, base = int(n[3]) >> 24, int(n[4])
+        for slot in range(8):
+            if (imask >> slot & 1) and base + slot == named[0]:
+                _, _, lo, hi = _planes(n)
+                assert (lo[slot] <= world.min(axis=0)).all() and (hi[slot] >= world.max(axis=0)).all()
+                assert ((hi[slot] - lo[slot]) < (world.max(axis=0) - world.min(axis=0)) * 1.2 + 0.1).all()
+                found = True
+    assert found
+    # the mesh's own nodes hold it untransformed
+    _, _, lo, hi = _planes(nodes[named[0]])
+    local = tris["p"].reshape(-1, 3).astype(np.float64)
+    used = (int(nodes[named[0], 3]) >> 24) | int(nodes[named[0], 6])
+    box_lo = np.min([lo[s] for s in range(8) if used >> s & 1], axis=0)
+    box_hi = np.max([hi[s] for s in range(8) if used >> s & 1], axis=0)
+    assert (box_lo <= local.min(axis=0)).all() and (box_hi >= local.max(axis=0)).all()
+    sc.close()
 
 
 def test_threaded_wide_build_is_deterministic(rt, ob):
