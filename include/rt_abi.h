@@ -236,8 +236,9 @@ int rt_scene_cache_state(const rt_scene* scene);   /* what the commit did: RT_CA
  * forms are the sweep (up to 192 entries) and the per-lane walk (out of LDS when the trees fit, else
  * from memory, plain or with idle lanes refilled); a scene of RT_BUILD_AUTO has the same forms on
  * its surface-area trees and, when those do not fit LDS, the wide walk over them.  What is decided
- * by rule (from measurements on every workload): the surface-area trees where the scene has them,
- * and the wide walk where it applies.  What is decided by timing, on the first render whose first
+ * by rule (from measurements on every workload): of two trees the one with the lower
+ * rt_scene_expected_cost() (the surface-area trees on every scene tried), and the wide walk where
+ * it applies.  What is decided by timing, on the first render whose first
  * batch has 8 Mi paths or more (that batch, once per candidate, output discarded): sweep against
  * walk out of LDS for scenes of up to 192 entries, plain against refilled walk for scenes walked
  * from memory without a wide tree.  A smaller frame runs on the likelier form and leaves the
@@ -288,6 +289,13 @@ int rt_scene_set_wide_build(rt_scene* scene, int where);
  * flattens them and uploads */
 int rt_scene_commit(rt_scene* scene);
 size_t rt_scene_num_prims(const rt_scene* scene);
+/* What a ray that enters the scene's bounds is expected to cost on the scene's trees (of a scene of
+ * RT_BUILD_AUTO: on its reference-topology trees), in box tests: the surface-area measure -- an entry
+ * is tested when the ray passes the box above it, for uniformly distributed rays with probability
+ * area(box) / area(scene bounds); a triangle test counts 1.6 box tests, a sphere test 1.3.  A scene
+ * of RT_BUILD_AUTO renders on whichever of its two trees has the lower figure.  0: not committed or
+ * not known (an empty or unbounded scene).  No counterpart in the reference. */
+double rt_scene_expected_cost(const rt_scene* scene);
 size_t rt_scene_num_entries(const rt_scene* scene);   /* flattened traversal entries */
 /* host-only scenes: copies the flattened pre-order entry array (16 floats per entry).  Word 3 of an
  * entry holds its kind in bits 30-31 (0 box, 1 triangle, 2 sphere) and, for a box, the index of the

@@ -97,6 +97,7 @@ def _load():
         "rt_context_num_devices": (i32, [vp]),
         "rt_context_set_reduce": (i32, [vp, i32]),
         "rt_rccl_version": (i32, []),
+        "rt_scene_expected_cost": (C.c_double, [vp]),
         "rt_context_destroy": (None, [vp]),
         "rt_last_error": (C.c_char_p, []),
         "rt_context_stream": (vp, [vp]),
@@ -170,7 +171,7 @@ def _load():
 
 lib = _load()
 ABI_SYMBOLS = [
-    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_set_reduce", "rt_rccl_version", "rt_context_destroy", "rt_last_error",
+    "rt_context_create", "rt_context_create_multi", "rt_context_num_devices", "rt_context_set_reduce", "rt_rccl_version", "rt_scene_expected_cost", "rt_context_destroy", "rt_last_error",
     "rt_context_stream", "rt_partition", "rt_render_multi", "rt_render_multi_device",
     "rt_context_synchronize", "rt_scene_create", "rt_scene_destroy", "rt_scene_set_materials",
     "rt_scene_add_spheres", "rt_scene_add_mesh", "rt_scene_begin_group", "rt_scene_end_group", "rt_scene_set_root", "rt_scene_set_build", "rt_set_default_build",
@@ -352,6 +353,11 @@ class Scene:
     @property
     def num_entries(self):
         return lib.rt_scene_num_entries(self.h)
+
+    @property
+    def expected_cost(self):
+        """Expected cost of a ray on the scene's (reference-topology, under BUILD_AUTO) trees, in box tests."""
+        return lib.rt_scene_expected_cost(self.h)
 
     # The flattened arrays name a primitive by its key (rt_abi.h, "Primitive keys").  The accessors
     # below return the arrays as the device holds them with raw=True; by default the key words are

@@ -180,6 +180,7 @@ struct SceneTree {
     bool ordered_ok = false;
     bool multi_child = false;           // a box with more than two children: no ordered walk (the octant walk is fine)
     bool lds_walk = false;              // the linked units fit the LDS of a workgroup
+    double expected_cost = 0.0;         // expected_cost_per_ray of its entries (0: not known)
     DeviceBuffer d_entries, d_units, d_walk, d_units_oct;
     DeviceBuffer d_wide_nodes, d_wide_prims;            // RT_TRAVERSAL_WIDE: made on first use
     WideScene wide;                                     // host-only scenes keep it for rt_scene_get_wide()
@@ -751,6 +752,7 @@ static void describe_tree(SceneTree& t, const FlatScene& f) {
     t.ordered_ok = f.ordered_ok;
     t.multi_child = f.multi_child;
     t.lds_walk = t.n_walk > 0 && ((size_t)t.n_walk + UNITS_END) * 16u <= LDS_WALK_MAX_BYTES && !std::getenv("RT_NO_LDS_WALK");
+    t.expected_cost = expected_cost_per_ray(f.entries.data(), f.n_entries());
 }
 
 // uploads one flattened tree to the GPU of s->ctx
@@ -914,6 +916,8 @@ int rt_scene_commit(rt_scene* s) {
     return RT_OK;
     RT_GUARD_END("rt_scene_commit")
 }
+
+double rt_scene_expected_cost(const rt_scene* s) { return s && s->committed ? s->trees[s->base_tree()].expected_cost : 0.0; }
 
 size_t rt_scene_num_prims(const rt_scene* s) { return s ? s->dev.n_prims : 0; }
 size_t rt_scene_num_entries(const rt_scene* s) { return s ? s->dev.n_entries : 0; }
@@ -1174,14 +1178,22 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
         const bool probe_all = std::getenv("RT_AUTO_PROBE_ALL") != nullptr;
         if (s->traversal == RT_TRAVERSAL_AUTO) {
             // The forms that report the reference's hits, on the trees the scene has (the base tree first: it
-            // keeps a draw).  A scene with a surface-area tree is timed on that tree only: on every workload
-            // and form measured it beat the median-split tree, by 1.07-2x.
+            // keeps a draw).  A scene with two trees runs on the one whose expected cost per ray (the
+            // surface-area measure over its boxes) is lower: the surface-area tree on every benchmark workload,
+            // where it beat the median-split tree in every form by 1.07-2x; the median-split tree where
+            // triangles are as large as their mesh and overlap throughout (per-lane walk 0.23 against 0.19 Grays/s).
             const int base = s->base_tree();
-            const bool fast = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present;
+            const bool two = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && s->trees[TREE_REFERENCE].present;
+            const double c_ref = s->trees[TREE_REFERENCE].expected_cost, c_fast = s->trees[TREE_FAST].expected_cost;
+            const int pick = !two ? base : (c_ref > 0.0 && c_fast > 0.0 && c_ref < c_fast && !std::getenv("RT_AUTO_FAST_TREE")) ? TREE_REFERENCE : TREE_FAST;
+            const bool fast = two;
+            if (std::getenv("RT_AUTOTUNE_LOG") && two)
+                std::fprintf(stderr, "[rt auto] expected cost per ray: reference tree %.2f, surface-area tree %.2f -> the %s tree\n", c_ref, c_fast,
+                             pick == TREE_FAST ? "surface-area" : "reference");
             for (int which : {base, 1 - base}) {
                 const SceneTree& t = s->trees[which];
                 if (!t.present) continue;
-                if (fast && which == TREE_REFERENCE && !probe_all) continue;
+                if (two && which != pick && !probe_all) continue;
                 if (t.n_entries <= SWEEP_MAX_ENTRIES && s->dev.n_xforms == 0) forms.push_back(Form{which, 1u, 0u, s->dev.prim_wait, 0u});
                 if (t.lds_walk) forms.push_back(Form{which, 0u, pinned_refill ? s->env_refill : 0u, s->dev.prim_wait, 0u});
                 else if (pinned_refill) forms.push_back(Form{which, 0u, s->env_refill, s->dev.prim_wait, 0u});
@@ -1191,14 +1203,14 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             // applies it is taken without a timing: on frames of real size it beat both binary walks on
             // every such scene measured (cornell_box.obj 1.15-1.4x, 10 M triangles 3.6x), and a timing of
             // three whole batches costs a one-frame job several times its frame.
-            if (fast && !s->trees[TREE_FAST].lds_walk && !std::getenv("RT_AUTO_NO_WIDE")) {
+            if (fast && !s->trees[pick].lds_walk && !std::getenv("RT_AUTO_NO_WIDE")) {
                 const int was = s->cur;
-                bind_tree(s, TREE_FAST);
+                bind_tree(s, pick);
                 const int wrc = ensure_wide_tree(s);
                 bind_tree(s, was);
                 if (wrc == RT_OK) {
                     if (!probe_all) forms.clear();
-                    forms.push_back(Form{TREE_FAST, 0u, pinned_refill ? s->env_refill : 16u, s->dev.prim_wait, 1u});
+                    forms.push_back(Form{pick, 0u, pinned_refill ? s->env_refill : 16u, s->dev.prim_wait, 1u});
                 } else if (wrc != RT_ERR_UNSUPPORTED) {
                     return wrc;
                 }

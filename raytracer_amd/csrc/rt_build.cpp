@@ -1178,4 +1178,62 @@ std::string build_flat_scene(const std::vector<rt_material>& mats, std::vector<S
     return std::string();
 }
 
+double expected_cost_per_ray(const float* entries, size_t n_entries) {
+    auto word = [&](size_t i, int w) { uint32_t u; std::memcpy(&u, entries + i * ENTRY_FLOATS + w, 4); return u; };
+    auto tag = [&](size_t i) { return word(i, 3) >> TAG_SHIFT; };
+    auto area = [&](size_t i) -> double {              // of a box entry
+        const float* e = entries + i * ENTRY_FLOATS;
+        const double dx = (double)e[4] - e[0], dy = (double)e[5] - e[1], dz = (double)e[6] - e[2];
+        const double a = dx * dy + dy * dz + dz * dx;
+        return a == a && a > 0.0 ? a : 0.0;
+    };
+    // the scene's bounds: the union of what stands at the top (boxes as stored, primitives by their extent)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (size_t i = 0; i < n_entries;) {
+        const float* e = entries + i * ENTRY_FLOATS;
+        const uint32_t t = tag(i);
+        if (t == TAG_BOX) {
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)e[k]); hi[k] = std::max(hi[k], (double)e[4 + k]); }
+            i = word(i, 3) & SKIP_MASK;
+        } else {
+            if (t == TAG_TRI)
+                for (int k = 0; k < 3; k++) {
+                    const double p0 = e[k], p1 = (double)e[k] + e[4 + k], p2 = (double)e[k] + e[8 + k];
+                    lo[k] = std::min(lo[k], std::min(p0, std::min(p1, p2))); hi[k] = std::max(hi[k], std::max(p0, std::max(p1, p2)));
+                }
+            else if (t == TAG_SPH)
+                for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)e[k] - std::fabs(e[4])); hi[k] = std::max(hi[k], (double)e[k] + std::fabs(e[4])); }
+            i++;                                       // (markers of transformed meshes: what follows is in the mesh's space)
+        }
+    }
+    const double rx = hi[0] - lo[0], ry = hi[1] - lo[1], rz = hi[2] - lo[2];
+    double root_area = rx * ry + ry * rz + rz * rx;
+    if (!(root_area > 0.0) || root_area != root_area) return 0.0;
+    struct Level { size_t end; double p; };            // p: the probability that an entry directly inside is tested
+    std::vector<Level> levels{Level{n_entries, 1.0}};
+    double cost = 0.0, p_enter = 1.0, norm = root_area;
+    bool inside_mesh = false;
+    for (size_t i = 0; i < n_entries; i++) {
+        while (levels.size() > 1 && levels.back().end <= i) levels.pop_back();
+        const double p = levels.back().p;
+        const uint32_t t = tag(i);
+        if (t == TAG_BOX) {
+            cost += p;
+            const double a = area(i);
+            if (inside_mesh && norm == 0.0) norm = a;  // the root box of a transformed mesh: areas inside count against it
+            const double hit = norm > 0.0 ? std::min(1.0, a / norm) : 1.0;
+            levels.push_back(Level{word(i, 3) & SKIP_MASK, (inside_mesh ? p_enter : 1.0) * hit});
+        } else if (t == TAG_TRI) {
+            cost += 1.6 * p;
+        } else if (t == TAG_SPH) {
+            cost += 1.3 * p;
+        } else if (word(i, 0) == END_CODE_ENTER) {
+            inside_mesh = true; p_enter = p; norm = 0.0;
+        } else if (word(i, 0) == END_CODE_LEAVE) {
+            inside_mesh = false; norm = root_area;
+        }
+    }
+    return cost;
+}
+
 }  // namespace rtamd

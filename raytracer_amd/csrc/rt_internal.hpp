@@ -192,6 +192,12 @@ struct WideScene {
     size_t n_nodes() const { return nodes.size() / node_words; }
     size_t n_prims() const { return prims.size() / WIDE_PRIM_FLOATS; }
 };
+// What a ray that enters the scene's bounds is expected to cost on a flattened tree, in box tests
+// (the surface-area measure: an entry is tested when the ray passes the box above it, which for
+// uniformly distributed rays happens with probability area(box) / area(root); a triangle test counts
+// 1.6 box tests, a sphere test 1.3).  What RT_BUILD_AUTO compares its two trees by.  0: not known.
+double expected_cost_per_ray(const float* entries, size_t n_entries);
+
 // collapses the pre-order entry array into a wide tree; returns an empty string on success.
 // `xforms`: FlatScene::xforms (32 floats per transformed mesh) when the array holds ENTER / LEAVE markers
 std::string build_wide_scene(const float* entries, size_t n_entries, WideScene& out, const float* xforms = nullptr,

@@ -95,6 +95,7 @@ extern "C" {
     pub fn rt_context_num_devices(ctx: *const rt_context) -> c_int;
     pub fn rt_context_set_reduce(ctx: *mut rt_context, mode: c_int) -> c_int;
     pub fn rt_rccl_version() -> c_int;
+    pub fn rt_scene_expected_cost(scene: *const rt_scene) -> f64;
     pub fn rt_context_destroy(ctx: *mut rt_context);
     pub fn rt_last_error() -> *const c_char;
     pub fn rt_context_stream(ctx: *mut rt_context) -> *mut c_void;

@@ -158,6 +158,7 @@ def main():
                     dd = (shown["d"].astype(np.float64) ** 2).sum(axis=1)
                     claimed = (dd > 1e-30) & (dd < 1e18)
                     differs = (got["prim_id"] != w["prim_id"]) | (hit & (got["t"].view(np.uint32) != w["t"].view(np.uint32)))
+                    differs &= ~(~np.isfinite(w["t"]) & ~np.isfinite(got["t"]))     # (hits whose t overflowed on both sides: ties, counted above)
                     if not (differs & claimed).any():
                         outside += int(differs.sum())
                         tie_log.append(f"{label} {name}: {int(differs.sum())} rays outside the claimed |d|^2 range differ")
