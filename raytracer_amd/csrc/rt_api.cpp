@@ -1185,7 +1185,12 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_render_params* 
             const int base = s->base_tree();
             const bool two = s->build_mode == RT_BUILD_AUTO && s->trees[TREE_FAST].present && s->trees[TREE_REFERENCE].present;
             const double c_ref = s->trees[TREE_REFERENCE].expected_cost, c_fast = s->trees[TREE_FAST].expected_cost;
-            const int pick = !two ? base : (c_ref > 0.0 && c_fast > 0.0 && c_ref < c_fast && !std::getenv("RT_AUTO_FAST_TREE")) ? TREE_REFERENCE : TREE_FAST;
+            // (a scene that will take the wide walk collapses the surface-area tree whatever the measure says: the
+            // collapse makes its own nodes, and over the surface-area tree they were the better ones on every scene
+            // measured -- 10 M triangles 1.34 against 1.26 Grays/s, cornell_box.obj 7.2 against 5.5, random
+            // transformed meshes 0.59 against 0.51 where the measure preferred the median-split tree)
+            const bool wide_tree = two && !s->trees[TREE_FAST].lds_walk && !std::getenv("RT_AUTO_NO_WIDE");
+            const int pick = !two ? base : (!wide_tree && c_ref > 0.0 && c_fast > 0.0 && c_ref < c_fast && !std::getenv("RT_AUTO_FAST_TREE")) ? TREE_REFERENCE : TREE_FAST;
             const bool fast = two;
             if (std::getenv("RT_AUTOTUNE_LOG") && two)
                 std::fprintf(stderr, "[rt auto] expected cost per ray: reference tree %.2f, surface-area tree %.2f -> the %s tree\n", c_ref, c_fast,

@@ -1,6 +1,6 @@
 """Rates of the forms that take transformed meshes on one scene (run on the GPU box): four meshes of
 `tris` triangles, three of them rotated, scaled and translated, and a few spheres under a sky.
-    python tools/xform_forms.py [tris per mesh]"""
+    python tools/xform_forms.py [tris per mesh] [plain]      # plain: the same meshes without their transforms"""
 import os
 import sys
 
@@ -14,6 +14,7 @@ from helpers import product_camera, random_mesh, random_scene
 from oracle import binding as ob
 
 tris = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+plain = len(sys.argv) > 2 and sys.argv[2] == "plain"
 rng = np.random.default_rng(11)
 mats, _, _ = random_scene(ob, 3)
 objects = []
@@ -24,7 +25,7 @@ for k in range(4):
     m[2, 2] = 1.0 + 0.25 * k
     m[:3, 3] = [3.0 * (k % 2) - 1.5, 3.0 * (k // 2) - 1.5, 0.5 * k]
     mesh = random_mesh(ob, rng, tris, 2.5)
-    objects.append(("mesh", mesh, m.T.reshape(16).copy()) if k != 3 else ("mesh", mesh))
+    objects.append(("mesh", mesh, m.T.reshape(16).copy()) if k != 3 and not plain else ("mesh", mesh))
 sp = np.zeros(30, dtype=ob.sphere_dt)
 sp["c"] = rng.uniform(-6, 6, (30, 3)).astype(np.float32)
 sp["r"] = rng.uniform(0.2, 0.8, 30).astype(np.float32)
@@ -52,7 +53,10 @@ for label, build, mode, env in (("reference tree, per-lane", rt.BUILD_REFERENCE,
         if i:
             best = min(best, st["ms_render"])
     sums.add(float(accum.double().sum()))
+    accum.zero_(); torch.cuda.synchronize()
+    ct = sc.render_device(pc, rt.Scene.params(w, h, 2, 6, osc.sky, flags=rt.RENDER_COUNT_VISITS), accum.data_ptr())
+    tests = f"{ct['box_tests'] / ct['rays_traced']:.0f} box + {ct['tri_tests'] / ct['rays_traced']:.0f} triangle tests per ray"
     print(f"{4 * tris} triangles, {label}: {st['rays_traced'] / best / 1e6:.2f} Grays/s ({best:.1f} ms), "
-          f"{rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree", flush=True)
+          f"{rt.FORM_NAMES[st['kernel_form']]} on the {rt.TREE_NAMES[st['tree']]} tree, {tests}", flush=True)
     sc.close()
 print("frames identical" if len(sums) == 1 else f"FRAMES DIFFER: {sums}")
