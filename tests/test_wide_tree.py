@@ -78,8 +78,18 @@ def _check_structure(nodes, prims, depth, entries):
     assert max_level == depth or (len(prims) == 0 and depth == 1)
 
 
-def _walk_wide(nodes, prims, o, d, t_min, t_max):
-    """Mirror of closest_hit_wide: returns (prim, t, node visits, primitive tests)."""
+_MARK = 0xFFFFFF00
+
+
+def _xf_apply(m, v, w):
+    """glam's transform_point3 (w = 1) / transform_vector3 (w = 0) on the 16 column-major floats m, in f32 steps."""
+    c = [[F(m[4 * j + i]) for i in range(3)] for j in range(4)]
+    return [F(F(c[3][i] * F(w)) + F(F(c[2][i] * v[2]) + F(F(c[1][i] * v[1]) + F(c[0][i] * v[0])))) for i in range(3)]
+
+
+def _walk_wide(nodes, prims, o, d, t_min, t_max, inverses=None):
+    """Mirror of closest_hit_wide: returns (prim, t, node visits, primitive tests).  `inverses`: the inverse
+    transforms (16 column-major floats each) of a scene with transformed meshes, by transform number."""
     pu = prims.view(np.uint32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         o, d = [F(x) for x in o], [F(x) for x in d]
@@ -87,14 +97,32 @@ def _walk_wide(nodes, prims, o, d, t_min, t_max):
         rb = sum(1 << k for k in range(3) if d[k] >= 0)
         best_t, best = F(t_max), 0xFFFFFFFF
         G, stack = 1 << rb, []
+        world = None
         n_nodes = n_prims = 0
         while (G & 0xFF) or stack:
             if not (G & 0xFF):
                 G = stack.pop()
+                if G == _MARK:                       # the mesh's subtree is exhausted: the caller's ray again
+                    o, d = world
+                    inv = [F(1.0) / d[k] for k in range(3)]
+                    rb = sum(1 << k for k in range(3) if d[k] >= 0)
+                    G = stack.pop() if stack else 0
+                    if not (G & 0xFF):
+                        continue
             p = (G & 0xFF).bit_length() - 1
             G ^= 1 << p
             node = nodes[(G >> 8) + (p ^ rb)]
             n_nodes += 1
+            if int(node[7]) >> 8:                    # the root of a transformed mesh's tree
+                world = (o, d)
+                if G & 0xFF:
+                    stack.append(G)
+                stack.append(_MARK)
+                G = 0
+                m = inverses[(int(node[7]) >> 8) - 1]
+                o, d = _xf_apply(m, o, 1.0), _xf_apply(m, d, 0.0)
+                inv = [F(1.0) / d[k] for k in range(3)]
+                rb = sum(1 << k for k in range(3) if d[k] >= 0)
             origin = node[0:3].view(np.float32)
             e = [int(node[3]) >> (8 * k) & 0xFF for k in range(3)]
             imask, lmask = int(node[3]) >> 24, int(node[6])
@@ -104,7 +132,7 @@ def _walk_wide(nodes, prims, o, d, t_min, t_max):
             bt = best_t if best_t == best_t else F(np.inf)
             dd = F(F(F(d[0] * d[0]) + F(d[1] * d[1])) + F(d[2] * d[2]))
             wild = not (dd < F(1e18) and dd > F(1e-30))
-            hm = int(node[7]) if wild else 0
+            hm = int(node[7]) & 0xFF if wild else 0
             for s in range(8):
                 tn, tf = F(t_min), bt
                 for k in range(3):
@@ -308,3 +336,49 @@ def test_wide_tree_of_nested_containers(rt, ob, root):
     want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
     assert (want["prim_id"] != 0xFFFFFFFF).sum() > 25
     assert _compare(nodes, prims, rays, want) <= 1
+
+
+@pytest.mark.parametrize("root,build", [(0, 0), (2, 0), (0, 1)])
+def test_wide_walk_through_transformed_meshes_on_the_cpu(rt, ob, root, build):
+    """The walk of a wide tree with transformed meshes, mirrored on the CPU (ray to the mesh's space at the
+    root of its tree, back when the subtree's marker comes off the stack), against the oracle.  The
+    inverses are computed here in double precision and rounded, not by the library's restatement of
+    glam's inverse, so t is compared to a few ulps of the transform's rounding instead of bit for bit
+    (the GPU tests do that: test_gpu_xform.py)."""
+    rng = np.random.default_rng(41 + root)
+    mats, _, _ = random_scene(ob, 9)
+    mats4 = []
+    objects = []
+    for k in range(3):
+        a = 0.5 * k + 0.3
+        m = np.eye(4)
+        m[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        m[2, 2] = 1.0 + 0.5 * k
+        m[0, 2] = 0.2 * k
+        m[:3, 3] = [2.5 * k - 2.5, 1.0 - k, 0.3 * k]
+        mats4.append(m)
+        objects.append(("mesh", random_mesh(ob, rng, 40, 2.0), m.astype(np.float32).T.reshape(16).copy()))
+    objects.append(("mesh", random_mesh(ob, rng, 30, 2.0)))
+    sp = np.zeros(9, dtype=ob.sphere_dt)
+    sp["c"] = rng.uniform(-5, 5, (9, 3)).astype(np.float32)
+    sp["r"] = rng.uniform(0.3, 0.9, 9).astype(np.float32)
+    sp["mat"] = rng.integers(0, 6, 9)
+    objects.append(("spheres", sp))
+    osc = ob.Scene.from_description(mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root, build=build)
+    nodes, prims, depth = sc.wide()
+    assert len(prims) == 150 + 9 and len(np.nonzero(nodes[:, 7] >> 8)[0]) == 3
+    inverses = [np.linalg.inv(m.astype(np.float32).astype(np.float64)).astype(np.float32).T.reshape(16) for m in mats4]
+    rays = random_rays(ob, 17, 400, -6.0, 6.0)
+    want, _ = osc.trace(rays, 0.001, np.inf, nthreads=1)
+    hits = want["prim_id"] != 0xFFFFFFFF
+    assert hits.sum() > 80
+    wrong = 0
+    for k in range(len(rays)):
+        prim, t, _, _ = _walk_wide(nodes, prims, rays["o"][k], rays["d"][k], F(0.001), F(np.inf), inverses)
+        if prim != int(want["prim_id"][k]):
+            wrong += 1
+        elif prim != 0xFFFFFFFF:
+            assert abs(float(t) - float(want["t"][k])) <= 2e-5 * max(1.0, abs(float(want["t"][k]))), k
+    assert wrong <= 2, wrong                      # (an inverse that differs in its last bit may move a hit across a tie)
+    sc.close()
