@@ -87,9 +87,10 @@ def _xf_apply(m, v, w):
     return [F(F(c[3][i] * F(w)) + F(F(c[2][i] * v[2]) + F(F(c[1][i] * v[1]) + F(c[0][i] * v[0])))) for i in range(3)]
 
 
-def _walk_wide(nodes, prims, o, d, t_min, t_max, inverses=None):
+def _walk_wide(nodes, prims, o, d, t_min, t_max, inverses=None, high_water=None):
     """Mirror of closest_hit_wide: returns (prim, t, node visits, primitive tests).  `inverses`: the inverse
-    transforms (16 column-major floats each) of a scene with transformed meshes, by transform number."""
+    transforms (16 column-major floats each) of a scene with transformed meshes, by transform number.
+    `high_water`: a one-element list that is raised to the largest number of words the stack ever held."""
     pu = prims.view(np.uint32)
     with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
         o, d = [F(x) for x in o], [F(x) for x in d]
@@ -118,6 +119,8 @@ def _walk_wide(nodes, prims, o, d, t_min, t_max, inverses=None):
                 if G & 0xFF:
                     stack.append(G)
                 stack.append(_MARK)
+                if high_water is not None:
+                    high_water[0] = max(high_water[0], len(stack))
                 G = 0
                 m = inverses[(int(node[7]) >> 8) - 1]
                 o, d = _xf_apply(m, o, 1.0), _xf_apply(m, d, 0.0)
@@ -157,6 +160,8 @@ def _walk_wide(nodes, prims, o, d, t_min, t_max, inverses=None):
             if ih:
                 if G & 0xFF:
                     stack.append(G)
+                    if high_water is not None:
+                        high_water[0] = max(high_water[0], len(stack))
                 G = int(node[4]) << 8 | ih
     return best, best_t, n_nodes, n_prims
 
@@ -382,3 +387,37 @@ def test_wide_walk_through_transformed_meshes_on_the_cpu(rt, ob, root, build):
             assert abs(float(t) - float(want["t"][k])) <= 2e-5 * max(1.0, abs(float(want["t"][k]))), k
     assert wrong <= 2, wrong                      # (an inverse that differs in its last bit may move a hit across a tie)
     sc.close()
+
+
+@pytest.mark.parametrize("seed", [3, 6, 9, 12, 15, 18])
+def test_wide_walk_stack_stays_within_the_recorded_depth(rt, ob, seed):
+    """The kernels give every lane one stack word per level of the wide tree (and one more for the marker
+    under a transformed mesh's subtree): the mirrored walk never holds more, on scenes of containers inside
+    containers with half of the meshes transformed, for random and adversarial rays, on both trees."""
+    from fuzz_parity import nested_objects
+    from helpers import adversarial_rays
+    rng = np.random.default_rng(seed)
+    mats, _, _ = random_scene(ob, seed)
+    objects = nested_objects(rng)
+    for build in (0, 1):
+        sc = rt.Scene(None, mats, objects, [0, 2][seed % 2], build=build)
+        nodes, prims, depth = sc.wide()
+        n_xf = len(np.nonzero(nodes[:, 7] >> 8)[0])
+        inverses = []                                  # numbered in the order the meshes were described
+
+        def collect(items):
+            for it in items:
+                if it[0] == "mesh" and len(it) > 2:
+                    m = np.asarray(it[2], dtype=np.float32).reshape(4, 4).T.astype(np.float64)
+                    inverses.append(np.linalg.inv(m).astype(np.float32).T.reshape(16))
+                elif it[0] in ("bvh", "list"):
+                    collect(it[1])
+        collect(objects)
+        assert len(inverses) == n_xf
+        rays = np.concatenate([random_rays(ob, seed, 120, -7.0, 7.0), adversarial_rays(ob, seed, 40, 7.0)])
+        mark = [0]
+        for k in range(len(rays)):
+            _walk_wide(nodes, prims, rays["o"][k], rays["d"][k], F(0.001), F(np.inf), inverses, mark)
+        assert mark[0] <= depth + (1 if n_xf else 0), (mark[0], depth, n_xf)
+        print(f"seed {seed} build {build}: depth {depth}, {n_xf} transformed meshes, stack high-water {mark[0]}")
+        sc.close()
