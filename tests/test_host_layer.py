@@ -666,7 +666,8 @@ def _walk_linked(units, o, d, t_min, t_max):
 
 @pytest.mark.parametrize("root", [0, 2])
 @pytest.mark.parametrize("top", ["0", "64", "100000"])
-def test_linked_units_keep_the_reference_order(rt, ob, root, top, monkeypatch):
+@pytest.mark.parametrize("build", [0, 1])
+def test_linked_units_keep_the_reference_order(rt, ob, root, top, build, monkeypatch):
     """The locality-ordered, explicitly linked units of the per-lane walks: every entry appears once,
     boxes and spheres are 32-byte aligned, the two children of a box lie side by side and a pair of
     boxes inside one 64-byte line, and following the links visits exactly the entries, in exactly the
@@ -674,7 +675,7 @@ def test_linked_units_keep_the_reference_order(rt, ob, root, top, monkeypatch):
     monkeypatch.setenv("RT_LAYOUT_TOP", top)
     mats, objects, _ = random_scene(ob, 51 + root, n_spheres=21, n_meshes=2, tris_per_mesh=37, extent=5.0)
     osc = ob.Scene.from_description(mats, objects, root)
-    sc = rt.Scene(None, mats, objects, root)
+    sc = rt.Scene(None, mats, objects, root, build=build)     # (the surface-area tree's units are laid out the same way)
     ent, units = sc.entries(), sc.walk_units()
     eu, uu = ent.view(np.uint32), units.view(np.uint32)
     n = len(ent)
